@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the YOLO-LP hot path on MI355X: images/s of (forward + decode + NMS [+ all-gather]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one per-GPU batch of synthetic 640x640 frames already resident in
+HBM: Model.forward through the HIP engine, lp_nms, and (N > 1) the RCCL all-gather of the padded detections.
+Rank 0 prints ONE JSON line.  Workload at N=1: BASELINE.json configs[1] (yololps 640x640 bs=32 fp16).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = 'images/sec (640×640) end-to-end detect+NMS, yololps, 1/2/4/8 MI355X'
+PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+SIGMA = {'yololps': 0.25, 'yololpn': 0.6, 'yolov6m': 0.25}       # predictor-weight scale of the synthetic recipe
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default='yololps', choices=list(SIGMA))
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'])
+    ap.add_argument('--conf', type=float, default=0.4)
+    ap.add_argument('--iou', type=float, default=0.45)
+    ap.add_argument('--max-det', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, sigma, size, conf, iou, max_det, budget_s):
+    """The oracle (CPU restatement of the reference path: torch fp32 forward + C NMS) timed on this host."""
+    import torch
+    from oracle import lp_oracle, lp_post
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(os.path.join(ROOT, 'configs', model_name + '.py'), sigma=sigma)
+    sd = {k: v.float() for k, v in m.state_dict().items()}
+    a = lp_oracle.arch(model_name)
+    B = 2
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(1234))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def step():
+        pred, _ = lp_oracle.forward(sd, a, x)
+        lp_post.nms_c(pred.numpy(), conf, iou, max_det)
+
+    step()                                             # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.time()
+    while True:
+        step()
+        n += 1
+        el = time.time() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {'value': round(n * B / el, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of %d images %dx%d, %s fp32, oracle/lp_oracle.py forward + oracle/lp_post_ref.c NMS, '
+                      '%d torch threads' % (n, B, size, size, model_name, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from yolov6.utils.synth import build_synthetic
+    from yolov6.hip import runtime
+    from yolov6.core.sharded import gather_detections
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    tdt = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}[args.dtype]
+    sigma = SIGMA[args.model]
+    model = build_synthetic(os.path.join(ROOT, 'configs', args.model + '.py'), sigma=sigma)
+    # the reference's inference preparation order: float -> fuse_model -> switch_to_deploy -> half (inferer.py:25-68)
+    from yolov6.utils.torch_utils import fuse_model
+    from yolov6.layers.common import RepVGGBlock
+    model = fuse_model(model).eval()
+    for layer in model.modules():
+        if isinstance(layer, RepVGGBlock):
+            layer.switch_to_deploy()
+    model = model.to(dev).to(tdt)
+    B = args.batch
+    x = torch.rand(B, 3, args.size, args.size, generator=torch.Generator().manual_seed(1234 + rank)).to(dev).to(tdt)
+    eng = runtime.engine_for(model)
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        pred = eng.forward(x)
+        det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
+        if world > 1:
+            gathered = gather_detections(det, count, out=gathered)
+            return gathered
+        return det, count
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    counts = out[1].float().mean().item()
+
+    result = None
+    if rank == 0:
+        # per-op device time (hipEvent pairs on torch's current stream, inside lp_engine_profile)
+        ops = eng.profile(x, reps=5)
+        t_nms = []
+        for _ in range(5):
+            pred = eng.forward(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
+            e1.record()
+            torch.cuda.synchronize()
+            t_nms.append(e0.elapsed_time(e1))
+        conv3 = [o for o in ops if o['kind'] == 'conv' and o['ksize'] == 3]
+        allmm = [o for o in ops if o['kind'] in ('conv', 'deconv', 'head_cls', 'head_box')]
+        fl3, ms3 = sum(o['flops'] for o in conv3), sum(o['ms'] for o in conv3)
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+        total_ms = sum(o['ms'] for o in ops)
+        roofline = {
+            'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': None,
+            'kernel': 'conv_mfma_kernel 3x3 (implicit GEMM, all %d launches of a step)' % len(conv3),
+            'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
+            'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
+            'all_mfma_kernels_tflops': round(sum(o['flops'] for o in allmm) / (sum(o['ms'] for o in allmm) * 1e-3) / 1e12, 2),
+            'forward_device_ms': round(total_ms, 3), 'nms_device_ms': round(sorted(t_nms)[len(t_nms) // 2], 3),
+            'forward_hbm_gbs': round(sum(o['bytes'] for o in ops) / (total_ms * 1e-3) / 1e9, 1),
+        }
+        result = {
+            'metric': METRIC, 'value': round(world * B * args.steps / elapsed, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d bs=%d/GPU %s, synthetic frames resident in HBM, seeded random-init weights '
+                                   '(sigma %.2f), conf %.2f iou %.2f max_det %d'
+                                   % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
+                       'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
+                       'mean_detections_per_image': round(counts, 1)},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.model, sigma, args.size, args.conf, args.iou, args.max_det,
+                                                  args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

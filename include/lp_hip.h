@@ -1,0 +1,145 @@
+/* lp_hip.h -- C ABI of libyololp_hip.so: the MI355X (gfx950) implementation of YOLO-LP's detection
+ * forward + decode + NMS hot path.
+ *
+ * The reference (KyleHuang9/YOLO-LP) is pure Python/PyTorch and has no FFI of its own; its boundary for this
+ * path is the Python module API.  This header is the C-ABI a binding for that API
+ * sits on: plain pointers and sizes, no torch types.  Each entry point names the reference interface it
+ * replaces (file:line relative to the reference repository).
+ *
+ * Conventions
+ *   - every function returns LP_OK (0) or a negative lp_status; lp_last_error() gives the message of the
+ *     last failure on the calling thread.  Nothing here falls back to a CPU path.
+ *   - all device pointers are caller-owned (the Python host allocates them as torch tensors); the library
+ *     allocates no device memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - activations inside an engine are NHWC with the channel count padded to a multiple of 8; the element
+ *     type is the engine's activation dtype (lp_dtype).  Accumulation is always fp32 (MFMA).
+ */
+#ifndef LP_HIP_H
+#define LP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LP_OK = 0, LP_ERR_ARG = -1, LP_ERR_STATE = -2, LP_ERR_HIP = -3, LP_ERR_UNSUPPORTED = -4 } lp_status;
+typedef enum { LP_F16 = 0, LP_BF16 = 1, LP_F32 = 2 } lp_dtype;
+typedef enum { LP_ACT_NONE = 0, LP_ACT_RELU = 1, LP_ACT_SILU = 2 } lp_act;
+
+#define LP_PRED_COLS 290   /* 4 xywh + 1 obj + 8 corners + 31 + 24 + 6*37 (effidehead.py:283-301) */
+#define LP_DET_COLS 28     /* xyxy + 8 corners + 8 conf + 8 idx (nms.py:94-96) */
+#define LP_MAX_SRC 4       /* inputs of one conv that are read as a channel concat without materialising it */
+
+typedef struct lp_engine lp_engine;
+
+const char* lp_version(void);
+const char* lp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Engine: a static graph of fused conv kernels over NHWC tensors, built once per model by the host from the
+ * model's folded weights, then run per batch.  Replaces Model.forward = backbone -> neck -> detect
+ * (yolov6/models/yolo.py:32-40) and everything below it (layers/common.py, models/efficientrep.py,
+ * models/reppan.py, models/effidehead.py:214-301, assigners/anchor_generator.py:11-31,
+ * utils/general.py:29-66).
+ * ------------------------------------------------------------------------------------------------- */
+int lp_engine_create(lp_engine** out, int act_dtype /* lp_dtype */);
+void lp_engine_destroy(lp_engine* e);
+
+/* Declare an activation tensor with `channels` channels at 1/2^stride_log2 of the input resolution.
+ * Returns its id (>= 0) or a negative lp_status. */
+int lp_engine_tensor(lp_engine* e, int channels, int stride_log2);
+
+/* The network input: caller's NCHW image batch [B,3,H,W] -> tensor `dst` (declared with 3 channels,
+ * stride_log2 0).  Must be the first op. */
+int lp_engine_add_input(lp_engine* e, int dst);
+
+typedef struct lp_conv_desc {
+    int n_src;              /* 1..LP_MAX_SRC; the sources are concatenated along channels in this order */
+    int src[LP_MAX_SRC];
+    int dst;
+    int ksize;              /* 1 or 3 (padding ksize/2) */
+    int stride;             /* 1 or 2 */
+    int act;                /* lp_act, applied after bias */
+    int res;                /* tensor id added after the activation (out = act(conv+b) + res_alpha*res), or -1 */
+    float res_alpha;
+    const float* weight;    /* host, fp32, [Cout][Cin_total][k][k]  (torch Conv2d.weight, BN already folded) */
+    const float* bias;      /* host, fp32, [Cout] */
+} lp_conv_desc;
+
+/* act(conv(cat(src...)) + bias) [+ alpha*res].  Replaces RepVGGBlock deploy forward (common.py:258-259),
+ * Conv/SimConv/Conv_C3.forward_fuse (common.py:41-42,65-66,475-476), the torch.cat feeding them
+ * (common.py:146-147,499,527; reppan.py:227-232) and BottleRep's residual (common.py:455). */
+int lp_engine_add_conv(lp_engine* e, const lp_conv_desc* d);
+
+/* 2x2 stride-2 transposed conv with bias: Transpose.forward (common.py:186-187).
+ * weight: host fp32 [Cin][Cout][2][2] (torch ConvTranspose2d.weight), bias [Cout]. */
+int lp_engine_add_deconv2x2(lp_engine* e, int src, int dst, const float* weight, const float* bias);
+
+/* Three chained 5x5 stride-1 pad-2 max pools (windows 5/9/13): the `self.m` calls of
+ * SimCSPSPPF/SimSPPF.forward (common.py:101-103,144-146).  dst1 = m(src), dst2 = m(dst1), dst3 = m(dst2). */
+int lp_engine_add_pool5_chain(lp_engine* e, int src, int dst1, int dst2, int dst3);
+
+/* Classification predictors of one pyramid level: the eight 1x1 convs + sigmoid of Detect.forward
+ * (effidehead.py:235-242,251-258) as ONE contraction; writes columns [13,13+n_cls) of the level's rows of
+ * pred.  weight: host fp32 [n_cls][C] (the eight predictor weights stacked in head order), bias [n_cls]. */
+int lp_engine_add_head_cls(lp_engine* e, int src, int level, int n_cls, const float* weight, const float* bias);
+
+/* Box + corner predictors of one level and the anchor-free decode: reg_preds / cor_preds 1x1 convs
+ * (effidehead.py:244-245), optional DFL softmax-projection (:247-249, reg_bins = reg_max+1 = 17, proj =
+ * proj_conv.weight[17]), generate_anchors (anchor_generator.py:11-31), dist2bbox 'xywh' and dist2cor
+ * (general.py:29-40,51-66), * stride (effidehead.py:285-286) and the objectness column of ones (:290).
+ * Writes columns [0,13) of the level's rows.  weight: host fp32 [4*reg_bins + 8][C], bias likewise.
+ * reg_bins = 1 means plain ltrb distances (use_dfl False). */
+int lp_engine_add_head_box(lp_engine* e, int src, int level, int reg_bins, const float* weight, const float* bias,
+                           const float* proj);
+
+/* Freeze the graph and pack the weights for the MFMA kernels (host side). */
+int lp_engine_finalize(lp_engine* e, int n_levels);
+size_t lp_engine_weight_bytes(const lp_engine* e);
+/* Copy the packed weights into caller-owned device memory (>= lp_engine_weight_bytes, 256-B aligned). */
+int lp_engine_upload(lp_engine* e, void* dev_weights, void* stream);
+
+/* Activation arena for a given input shape (H, W multiples of 32). */
+size_t lp_engine_arena_bytes(const lp_engine* e, int B, int H, int W);
+int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B, int H, int W);
+/* Placement of tensor `id` inside the bound arena: byte offset, logical channels, stored channels (padded
+ * to 8), height, width.  Layout is [B][h][w][c_stored] of the activation dtype. */
+int lp_engine_tensor_info(const lp_engine* e, int id, size_t* offset, int* c, int* c_stored, int* h, int* w);
+/* Rows of pred per image (sum over levels of h*w) for the bound shape. */
+int lp_engine_num_anchors(const lp_engine* e);
+
+/* Run the graph on the bound shape.  x: device [B,3,H,W] of x_dtype (lp_dtype); pred: device fp32
+ * [B, num_anchors, LP_PRED_COLS].  Model.forward's first return value (yolo.py:40); the second one (the
+ * three neck maps) stays in the arena (lp_engine_tensor_info). */
+int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream);
+
+/* Introspection for benchmarks: ops of the frozen graph and per-op device time (hipEvent pairs on
+ * `stream`, one untimed warm run first).  op_ms has lp_engine_num_ops() entries (milliseconds). */
+int lp_engine_num_ops(const lp_engine* e);
+/* kind: 0 input, 1 conv, 2 deconv, 3 pool, 4 head_cls, 5 head_box.  flops = 2*MAC of the op on the bound
+ * shape; bytes = algorithmic activation bytes read + written (each tensor once) + weight bytes. */
+int lp_engine_op_info(const lp_engine* e, int op, int* kind, int* ksize, int* cin, int* cout, double* flops,
+                      double* bytes);
+int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Post-processing.  Replaces non_max_suppression (yolov6/utils/nms.py:31-130) including its call of
+ * torchvision.ops.nms (:121).  All images of the batch are processed by one set of launches.
+ *   pred      device fp32 [B,N,290]; columns 13.. are multiplied by column 4 IN PLACE (nms.py:76)
+ *   conf/iou  thresholds as the python floats the reference receives (conf is compared in fp32, iou in
+ *             double, as torch / torchvision do)
+ *   det       device fp32 [B,max_det,28], rows in descending-score order; rows >= count[b] are zero
+ *   count     device int32 [B]
+ *   keep      device int32 [B,max_det] anchor index of every kept row, or NULL
+ *   workspace device scratch of at least lp_nms_workspace_bytes(B,N) bytes
+ * ------------------------------------------------------------------------------------------------- */
+size_t lp_nms_workspace_bytes(int B, int N);
+int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det, int32_t* count,
+           int32_t* keep, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LP_HIP_H */

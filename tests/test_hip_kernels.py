@@ -1,0 +1,189 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(via yolov6.hip.runtime.Engine, the ctypes host).  The checker is the CPU
+oracle: plain torch fp32 ops for the float kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lp_testing import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+# stated tolerances (relative to the largest reference magnitude): fp32 engine = exact-fp32 MFMA with a
+# different summation order; fp16 / bf16 = inputs, weights and outputs rounded to 11 / 8 significant bits
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def _engine(dtype):
+    from yolov6.hip.runtime import Engine
+    return Engine(dtype, 'cuda:0')
+
+
+def _fill(eng, tid, ref_nchw):
+    """Write an NCHW fp32 reference tensor into arena tensor ``tid`` (all stored channels, padding = 0)."""
+    v = eng.tensor_view(tid)                                     # [B,C,h,w] view, logical channels
+    v.copy_(ref_nchw.to(v.device, v.dtype))
+
+
+def _run(eng, B, H, W):
+    x = torch.zeros(B, 3, H, W, device='cuda:0')
+    return eng.forward(x)
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+CONV_CASES = [
+    # (cin list, cout, k, s, act, residual, H, W at the source resolution, B)
+    ([64], 64, 3, 1, 'relu', False, 40, 40, 2),        # CFG_B, exact tiles
+    ([128], 128, 3, 1, 'relu', False, 20, 20, 3),      # CFG_A, ragged 20x20 map
+    ([32], 64, 3, 2, 'relu', False, 64, 48, 2),        # stride 2
+    ([3], 32, 3, 2, 'relu', False, 64, 64, 2),         # stem-like: 3 real channels of 8 stored
+    ([64, 64], 128, 3, 1, 'relu', False, 24, 16, 2),   # two sources (concat-free PAN input)
+    ([256], 128, 1, 1, 'relu', False, 20, 20, 2),      # 1x1 reduce
+    ([64, 64, 64, 64], 64, 1, 1, 'relu', False, 12, 20, 2),   # SPPF cv5: four sources
+    ([128, 64, 64], 64, 1, 1, 'silu', False, 16, 16, 1),
+    ([96], 96, 3, 1, 'relu', True, 16, 24, 2),         # BottleRep residual, cout not a tile multiple
+    ([40], 24, 3, 1, 'none', False, 8, 8, 1),  # small odd channel counts (8-multiples)
+    ([5], 5, 3, 1, 'relu', True, 8, 8, 1),             # logical channels not a multiple of 8 (padded storage)
+    ([16], 8, 1, 1, 'silu', False, 8, 8, 1),           # CFG_C
+    ([512], 512, 3, 1, 'relu', False, 20, 20, 1),      # deep K (4608)
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: '%s-%d-k%ds%d-%s%s' % ('+'.join(map(str, c[0])), c[1], c[2], c[3], c[4], '-res' if c[5] else ''))
+def test_conv(case, dtype):
+    from yolov6.hip import abi
+    cins, cout, k, s, act, use_res, h, w, B = case
+    sl = 2
+    eng = _engine(dtype)
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, k, k), 1, (2.0 / (cin * k * k)) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    res_id = eng.tensor(cout, sl) if use_res else None
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, bias, k, s, act_id, sl, res=res_id, alpha=0.75)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    xs = [_rand((B, c, h, w), 10 + i) for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()                     # what the engine actually stores
+    for t, x in zip(srcs, xs):
+        _fill(eng, t, x)
+    res = _rand((B, cout, h // s, w // s), 20) if use_res else None
+    if use_res:
+        _fill(eng, res_id, res)
+    _run(eng, B, H, W)
+    got = eng.tensor_view(dst).float().cpu()
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(wt), bias, stride=s, padding=k // 2)
+    ref = {'none': lambda t: t, 'relu': F.relu, 'silu': F.silu}[act](ref)
+    if use_res:
+        ref = q(ref) + 0.75 * q(res) if dtype != torch.float32 else ref + 0.75 * res
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= TOL[dtype], rel_err(got, ref)
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cin,cout,h,w', [(128, 128, 20, 20), (64, 64, 10, 14), (16, 24, 6, 6)])
+def test_deconv2x2(cin, cout, h, w, dtype):
+    import ctypes
+    from yolov6.hip import abi
+    from yolov6.hip.runtime import _f32
+    eng = _engine(dtype)
+    src, dst = eng.tensor(cin, 3), eng.tensor(cout, 2)
+    wt = _rand((cin, cout, 2, 2), 3, (1.0 / cin) ** 0.5)
+    bias = _rand((cout,), 4, 0.5)
+    abi.check(eng.lib.lp_engine_add_deconv2x2(eng.h, src, dst, eng._ptr(_f32(wt)), eng._ptr(_f32(bias))))
+    eng.finish()
+    B = 2
+    eng.bind(B, h * 8, w * 8)
+    x = _rand((B, cin, h, w), 5)
+    _fill(eng, src, x)
+    _run(eng, B, h * 8, w * 8)
+    got = eng.tensor_view(dst).float().cpu()
+    q = lambda t: t.to(dtype).float()
+    ref = F.conv_transpose2d(q(x), q(wt), bias, stride=2)
+    assert rel_err(got, ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('c,h,w', [(256, 20, 20), (64, 13, 7), (8, 4, 3), (40, 40, 40)])
+def test_pool_chain(c, h, w, dtype):
+    from yolov6.hip import abi
+    eng = _engine(dtype)
+    ids = [eng.tensor(c, 5) for _ in range(4)]
+    abi.check(eng.lib.lp_engine_add_pool5_chain(eng.h, *ids))
+    eng.finish()
+    B = 2
+    eng.bind(B, h * 32, w * 32)
+    x = _rand((B, c, h, w), 6).to(dtype).float()
+    _fill(eng, ids[0], x)
+    _run(eng, B, h * 32, w * 32)
+    y = x
+    for t in ids[1:]:
+        y = F.max_pool2d(y, 5, 1, 2)
+        assert torch.equal(eng.tensor_view(t).float().cpu(), y)      # max is exact in every dtype
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('xdtype', [torch.float32, torch.float16])
+def test_input_layout(dtype, xdtype):
+    eng = _engine(dtype)
+    eng.finish()
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(7)).to(xdtype)
+    eng.forward(x.cuda())
+    got = eng.tensor_view(eng.input_id).float().cpu()
+    assert torch.equal(got, x.float().to(dtype).float())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('bins', [1, 17])
+def test_head(dtype, bins):
+    """head_cls (8 predictors + sigmoid) and head_box (+DFL) + decode against the oracle's decode."""
+    from yolov6.hip import abi
+    from yolov6.hip.runtime import _f32
+    from oracle import lp_oracle
+    C, B, H, W = 64, 2, 128, 96
+    eng = _engine(dtype)
+    feats = [eng.tensor(C, 3 + i) for i in range(3)]
+    ws = []
+    for i, f in enumerate(feats):
+        wc, bc = _rand((277, C), 30 + i, 0.3), _rand((277,), 40 + i, 1.0)
+        wb, bb = _rand((4 * bins + 8, C), 50 + i, 0.2), _rand((4 * bins + 8,), 60 + i, 1.0)
+        proj = torch.linspace(0, bins - 1, bins)
+        abi.check(eng.lib.lp_engine_add_head_cls(eng.h, f, i, 277, eng._ptr(_f32(wc)), eng._ptr(_f32(bc))))
+        abi.check(eng.lib.lp_engine_add_head_box(eng.h, f, i, bins, eng._ptr(_f32(wb)), eng._ptr(_f32(bb)),
+                                                 eng._ptr(_f32(proj)) if bins > 1 else None))
+        ws.append((wc, bc, wb, bb, proj))
+    eng.finish()
+    eng.bind(B, H, W)
+    xs = [_rand((B, C, H >> (3 + i), W >> (3 + i)), 70 + i) for i in range(3)]
+    for f, x in zip(feats, xs):
+        _fill(eng, f, x)
+    pred = _run(eng, B, H, W).cpu()
+    q = lambda t: t.to(dtype).float()
+    cls_all, reg_all, cor_all = [], [], []
+    for (wc, bc, wb, bb, proj), x in zip(ws, xs):
+        l = x.shape[2] * x.shape[3]
+        cls_all.append(torch.sigmoid(F.conv2d(q(x), q(wc)[..., None, None], bc)).reshape(B, 277, l))
+        o = F.conv2d(q(x), q(wb)[..., None, None], bb)
+        reg = o[:, :4 * bins]
+        if bins > 1:
+            reg = F.conv2d(F.softmax(reg.reshape(B, 4, bins, l).permute(0, 2, 1, 3), dim=1), proj.reshape(1, bins, 1, 1))
+        reg_all.append(reg.reshape(B, 4, l))
+        cor_all.append(o[:, 4 * bins:].reshape(B, 8, l))
+    cat = lambda p: torch.cat(p, -1).permute(0, 2, 1)
+    pts, st = lp_oracle.anchors([x.shape[2:] for x in xs])
+    box, corners = lp_oracle.decode(cat(reg_all), cat(cor_all), pts, st)
+    ref = torch.cat([box, torch.ones(B, box.shape[1], 1), corners, cat(cls_all)], -1)
+    assert pred.shape == ref.shape
+    assert torch.equal(pred[..., 4], torch.ones_like(pred[..., 4]))
+    tol = TOL[dtype]
+    assert float((pred[..., 13:] - ref[..., 13:]).abs().max()) <= tol * 2            # probabilities
+    scale = float(ref[..., :13].abs().max())
+    assert float((pred[..., :13] - ref[..., :13]).abs().max()) <= tol * scale * (4 if bins > 1 else 2)

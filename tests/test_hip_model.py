@@ -1,0 +1,190 @@
+"""GPU parity tests of the whole hot path: Model.forward through the HIP engine
+and non_max_suppression through lp_nms, against the CPU oracle (oracle/) and the
+golden vectors recorded from the reference (tests/golden/)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, REPO
+from lp_testing import synth_pred, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CFG = lambda n: os.path.join(REPO, 'configs', n + '.py')   # noqa: E731
+MODEL_CASES = [('lps_tiny_128x96', 'lps_tiny_weights', 'yololps'),
+               ('lps_tiny_64x160', 'lps_tiny_weights', 'yololps'),
+               ('v6m_tiny_96x128', 'v6m_tiny_weights', 'yolov6m')]
+
+
+def _tiny_model(name, weights, deploy):
+    from yolov6.utils.synth import build_synthetic
+    from yolov6.utils.torch_utils import fuse_model
+    from yolov6.layers.common import RepVGGBlock
+    m = build_synthetic(CFG(name), width=0.0625, sigma=1.5)
+    m.load_state_dict(load_golden(weights))
+    if deploy:                                       # the reference's inference preparation (inferer.py:25-68)
+        m = fuse_model(m).eval()
+        for layer in m.modules():
+            if isinstance(layer, RepVGGBlock):
+                layer.switch_to_deploy()
+    return m.eval()
+
+
+def _check_pred(pred, ref, box_tol, prob_tol):
+    """boxes / key-points: |d| <= box_tol * max(1,|ref|) (the north-star 1e-4 read relative to the coordinate
+    magnitude: the reference's own fused-vs-unfused forward differs by up to 4e-4 absolute on these cases);
+    probabilities: absolute."""
+    assert pred.shape == ref.shape and pred.dtype == torch.float32
+    assert torch.equal(pred[..., 4], torch.ones_like(pred[..., 4]))
+    c, r = pred[..., :13].double(), ref[..., :13].double()
+    assert float(((c - r).abs() / r.abs().clamp(min=1.0)).max()) <= box_tol
+    assert float((pred[..., 13:] - ref[..., 13:]).abs().max()) <= prob_tol
+
+
+@pytest.mark.parametrize('deploy', [True, False], ids=['deploy', 'unfused'])
+@pytest.mark.parametrize('case,weights,name', MODEL_CASES)
+def test_tiny_model_fp32_matches_reference_golden(case, weights, name, deploy):
+    g = load_golden(case)
+    m = _tiny_model(name, weights, deploy).cuda()
+    with torch.no_grad():
+        pred, feats = m(g['x'].cuda())
+    _check_pred(pred.cpu(), g['pred'], 1e-4, 1e-4)
+    for i, f in enumerate(feats):
+        ref = g['neck%d' % i]
+        assert f.shape == ref.shape
+        assert rel_err(f.float().cpu(), ref) <= 1e-4
+
+
+@pytest.mark.parametrize('dtype,box_tol,prob_tol', [(torch.float16, 2e-2, 2e-2), (torch.bfloat16, 1.5e-1, 1.5e-1)])
+@pytest.mark.parametrize('case,weights,name', MODEL_CASES)
+def test_tiny_model_half_precision(case, weights, name, dtype, box_tol, prob_tol):
+    """fp16 / bf16 engines: activations and weights are rounded at every layer, so the stated tolerance is
+    that of ~40 chained 11-bit / 8-bit roundings, not 1e-4."""
+    g = load_golden(case)
+    m = _tiny_model(name, weights, True).cuda().to(dtype)
+    with torch.no_grad():
+        pred, feats = m(g['x'].cuda().to(dtype))
+    assert feats[0].dtype == dtype
+    _check_pred(pred.cpu(), g['pred'], box_tol, prob_tol)
+
+
+@pytest.mark.parametrize('name,B,H,W', [('yololps', 2, 640, 640), ('yololpn', 3, 640, 416), ('yolov6m', 1, 320, 320)])
+def test_full_model_fp32_vs_oracle(name, B, H, W):
+    from oracle import lp_oracle
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG(name), sigma=0.25)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    ref, ref_feats = lp_oracle.forward(m.state_dict(), lp_oracle.arch(name), x)
+    with torch.no_grad():
+        pred, feats = m.cuda()(x.cuda())
+    assert pred.shape == (B, (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32), 290)
+    _check_pred(pred.cpu(), ref, 2e-4, 2e-4)
+    for f, rf in zip(feats, ref_feats):
+        assert rel_err(f.float().cpu(), rf) <= 1e-4
+
+
+def test_full_model_fp16_vs_oracle_and_determinism():
+    from oracle import lp_oracle
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), sigma=0.25)
+    x = torch.rand(2, 3, 640, 640, generator=torch.Generator().manual_seed(1234))
+    ref, _ = lp_oracle.forward(m.state_dict(), lp_oracle.arch('yololps'), x)
+    mh = m.cuda().half()
+    with torch.no_grad():
+        p1, _ = mh(x.cuda().half())
+        p1 = p1.clone()
+        p2, _ = mh(x.cuda().half())
+    assert torch.equal(p1, p2)                       # no atomics / split-K: bitwise reproducible
+    _check_pred(p1.cpu(), ref, 3e-2, 3e-2)
+    # batch independence: image 1 alone gives the same rows as image 1 inside the batch
+    with torch.no_grad():
+        p3, _ = mh(x[1:2].cuda().half())
+    assert torch.equal(p3[0], p1[1])
+
+
+def test_cuda_path_fails_loudly_without_extension(monkeypatch):
+    from yolov6.hip import abi
+    monkeypatch.setattr(abi, '_lib', None)
+    monkeypatch.setattr(abi, 'LIB_PATH', '/nonexistent/libyololp_hip.so')
+    with pytest.raises(RuntimeError, match='missing'):
+        abi.load()
+
+
+# ---------------------------------------------------------------------------------------------------
+NMS_CASES = ['nms_model_tiny', 'nms_synth_600', 'nms_synth_maxdet5', 'nms_synth_obj', 'nms_crafted', 'nms_empty']
+
+
+@pytest.mark.parametrize('case', NMS_CASES)
+def test_nms_golden_bit_exact(case):
+    from yolov6.utils.nms import non_max_suppression
+    g = load_golden(case)
+    p = g['pred'].clone().cuda()
+    out = non_max_suppression(p, float(g['conf']), float(g['iou']), max_det=int(g['max_det']))
+    assert len(out) == p.shape[0]
+    for b, o in enumerate(out):
+        assert o.is_cuda and o.dtype == torch.float32 and o.shape[1] == 28
+        assert torch.equal(o.cpu(), g['det%d' % b]), case
+    if 'pred_after' in g:                            # in-place obj*cls product on the caller's tensor
+        assert torch.equal(p.cpu(), g['pred_after'])
+    else:
+        assert torch.equal(p.cpu(), g['pred'])
+
+
+@pytest.mark.parametrize('B,N,seed,hot,conf,iou,max_det,obj_one', [
+    (4, 8400, 21, 0.05, 0.4, 0.45, 1000, True),        # infer defaults
+    (2, 8400, 22, 0.30, 0.03, 0.65, 300, True),        # eval defaults: every anchor is a candidate
+    (3, 2100, 23, 0.50, 0.25, 0.50, 50, False),        # obj != 1, truncation by max_det
+    (1, 33600, 24, 0.02, 0.4, 0.45, 1000, True),       # 1280x1280 anchor count
+    (2, 77, 25, 1.00, 0.30, 0.10, 1000, True),         # fewer anchors than a wave
+])
+def test_nms_random_vs_oracle_bit_exact(B, N, seed, hot, conf, iou, max_det, obj_one):
+    from oracle import lp_post
+    from yolov6.hip.runtime import nms_padded
+    pred = synth_pred(B, N, seed, frac_hot=hot, obj_one=obj_one)
+    rows, keep, after = lp_post.nms_c(pred.numpy(), conf, iou, max_det)
+    p = pred.clone().cuda()
+    det, count, kept = nms_padded(p, conf, iou, max_det, want_keep=True)
+    det, count, kept = det.cpu().numpy(), count.cpu().numpy(), kept.cpu().numpy()
+    assert count.tolist() == [len(r) for r in rows]
+    for b in range(B):
+        n = count[b]
+        assert np.array_equal(kept[b, :n], keep[b])            # bit-exact index selection, in order
+        assert np.array_equal(det[b, :n], rows[b])
+        assert not det[b, n:].any() and (kept[b, n:] == -1).all()
+    assert np.array_equal(p.cpu().numpy(), after)
+    # idempotence of the selection: feeding only the kept anchors back keeps all of them, in the same order
+    b0 = 0
+    if 0 < count[b0] <= 1000 and obj_one:
+        sub = pred[b0:b0 + 1, torch.from_numpy(keep[b0].astype(np.int64))].clone().cuda()
+        det2, count2, kept2 = nms_padded(sub, conf, iou, max_det, want_keep=True)
+        assert int(count2[0]) == count[b0]
+        assert kept2[0, :count[b0]].cpu().tolist() == list(range(count[b0]))
+
+
+def test_nms_on_engine_output_matches_oracle():
+    """End to end on one batch: pred from the HIP engine, NMS by lp_nms == oracle NMS of that same pred."""
+    from oracle import lp_post
+    from yolov6.utils.synth import build_synthetic
+    from yolov6.utils.nms import non_max_suppression
+    m = build_synthetic(CFG('yololps'), sigma=0.25).cuda().half()
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(99)).cuda().half()
+    with torch.no_grad():
+        pred, _ = m(x)
+    rows, keep, _ = lp_post.nms_c(pred.cpu().numpy(), 0.4, 0.45, 1000)
+    out = non_max_suppression(pred, 0.4, 0.45, max_det=1000)
+    assert sum(len(r) for r in rows) > 0
+    for o, r in zip(out, rows):
+        assert np.array_equal(o.cpu().numpy(), r)
+
+
+def test_nms_rejects_bad_arguments():
+    from yolov6.utils.nms import non_max_suppression
+    from yolov6.hip.runtime import nms_padded
+    with pytest.raises(AssertionError):
+        non_max_suppression(torch.zeros(1, 8, 290, device='cuda'), conf_thres=2.0)
+    with pytest.raises(ValueError):
+        nms_padded(torch.zeros(1, 8, 100, device='cuda'), 0.4, 0.45, 10)
+    out = non_max_suppression(torch.zeros(2, 0, 290, device='cuda'))
+    assert [tuple(o.shape) for o in out] == [(0, 28), (0, 28)]

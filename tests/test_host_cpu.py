@@ -1,0 +1,115 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header declares,
+the engine graph of every BASELINE config builds and packs (host code only, no kernel is launched), argument
+validation of the ABI, and the sharding / all-gather logic over gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def test_abi_exports_every_declared_symbol():
+    from yolov6.hip import abi
+    lib = abi.load()
+    header = open(os.path.join(REPO, 'include', 'lp_hip.h')).read()
+    declared = set(re.findall(r'\b(lp_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.lp_version().startswith(b'yololp-hip')
+
+
+def test_abi_argument_validation():
+    from yolov6.hip import abi
+    lib = abi.load()
+    h = ctypes.c_void_p()
+    assert lib.lp_engine_create(ctypes.byref(h), 7) < 0
+    assert lib.lp_engine_create(ctypes.byref(h), abi.LP_F16) == 0
+    assert lib.lp_engine_tensor(h, 0, 0) < 0 and b'bad shape' in lib.lp_last_error()
+    t0 = lib.lp_engine_tensor(h, 3, 0)
+    t1 = lib.lp_engine_tensor(h, 16, 1)
+    assert lib.lp_engine_finalize(h, 3) < 0                          # no input op yet
+    assert lib.lp_engine_add_input(h, t1) < 0                        # must be 3 channels at full resolution
+    assert lib.lp_engine_add_input(h, t0) == 0
+    assert lib.lp_engine_add_input(h, t0) < 0                        # only once, first
+    d = abi.ConvDesc()
+    d.n_src, d.dst, d.ksize, d.stride, d.act, d.res = 1, t1, 5, 1, 0, -1
+    d.src[0] = t0
+    w = (ctypes.c_float * (16 * 3 * 25))()
+    b = (ctypes.c_float * 16)()
+    d.weight, d.bias = ctypes.cast(w, ctypes.c_void_p), ctypes.cast(b, ctypes.c_void_p)
+    assert lib.lp_engine_add_conv(h, ctypes.byref(d)) == -4         # 5x5: unsupported
+    d.ksize, d.stride = 3, 1
+    assert lib.lp_engine_add_conv(h, ctypes.byref(d)) < 0            # stride 1 cannot halve the resolution
+    d.stride = 2
+    assert lib.lp_engine_add_conv(h, ctypes.byref(d)) == 0
+    assert lib.lp_engine_finalize(h, 3) == 0
+    assert lib.lp_engine_tensor(h, 8, 1) < 0                         # frozen
+    assert lib.lp_engine_weight_bytes(h) > 0
+    assert lib.lp_engine_arena_bytes(h, 1, 100, 64) == 0             # not a multiple of 32
+    assert lib.lp_engine_arena_bytes(h, 2, 64, 96) > 0
+    assert lib.lp_engine_forward(h, None, 0, None, None) < 0         # nothing uploaded / bound
+    lib.lp_engine_destroy(h)
+    assert lib.lp_nms_workspace_bytes(32, 8400) > 32 * 8400 * 28 * 4
+    assert lib.lp_nms(None, 1, 1, 0.4, 0.45, 10, None, None, None, None, 0, None) < 0
+
+
+@pytest.mark.parametrize('name,n_ops,weight_mb', [('yololps', 73, 37.3), ('yololpn', 73, 9.4), ('yolov6m', 110, 70.0)])
+def test_engine_graph_builds_for_baseline_configs(name, n_ops, weight_mb):
+    from yolov6.hip.runtime import Engine
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(os.path.join(REPO, 'configs', name + '.py'))
+    eng = Engine.from_model(m, torch.float16, 'cpu')                 # host part only: graph + weight packing
+    assert eng.lib.lp_engine_num_ops(eng.h) == n_ops
+    # packed fp16 weights ~ the reference's fused parameter bytes (37.26 / 9.39 / 69.99 MB) + padding
+    assert weight_mb <= eng.weight_bytes / 1e6 <= weight_mb * 1.05
+
+
+def test_shard_bounds_cover_the_batch():
+    from yolov6.core.sharded import shard_bounds
+    for B in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from yolov6.core.sharded import gather_detections, shard_bounds, unpad
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'], rank=rank, world_size=world)
+B, max_det = 6, 5
+g = torch.Generator().manual_seed(0)
+det_full = torch.rand(B, max_det, 28, generator=g)
+cnt_full = torch.randint(0, max_det + 1, (B,), generator=g, dtype=torch.int32)
+lo, hi = shard_bounds(B, rank, world)
+det_all, cnt_all = gather_detections(det_full[lo:hi].clone(), cnt_full[lo:hi].clone())
+assert torch.equal(det_all, det_full) and torch.equal(cnt_all, cnt_full), rank
+outs = unpad(det_all, cnt_all)
+assert [len(o) for o in outs] == cnt_full.tolist()
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_gather_detections_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % REPO)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

@@ -1,0 +1,126 @@
+// Bandwidth-bound helper kernels of the engine: network input re-layout and the SPPF pool chain.
+#include "lp_internal.h"
+
+namespace lp {
+
+// ---- input: caller's NCHW [B,3,H,W] (fp32 / fp16 / bf16) -> NHWC with 8 stored channels (3 real + 5 zero)
+// of the activation dtype.  One thread per pixel: three coalesced plane reads, one 16-/32-byte row write.
+// Replaces the implicit layout of the first conv's input (yolov6/models/yolo.py:34).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void input_kernel(const TI* __restrict__ x, TO* __restrict__ dst, int B, long long HW) {
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const TI* xp = x + b * 3 * HW + p;
+        TO row[8] __attribute__((aligned(16)));
+        row[0] = (TO)(float)xp[0];
+        row[1] = (TO)(float)xp[HW];
+        row[2] = (TO)(float)xp[2 * HW];
+#pragma unroll
+        for (int k = 3; k < 8; ++k) row[k] = (TO)0.f;
+        uint4* o = (uint4*)(dst + i * 8);
+        const uint4* rv = (const uint4*)row;
+#pragma unroll
+        for (int k = 0; k < (int)(8 * sizeof(TO) / 16); ++k) o[k] = rv[k];
+    }
+}
+
+template <typename TI>
+static int input_launch_to(const void* x, void* dst, int dtype, int B, int H, int W, hipStream_t st) {
+    const long long HW = (long long)H * W;
+    long long blocks = ((long long)B * HW + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    switch (dtype) {
+        case LP_F16: hipLaunchKernelGGL((input_kernel<TI, f16>), grid, dim3(256), 0, st, (const TI*)x, (f16*)dst, B, HW); break;
+        case LP_BF16: hipLaunchKernelGGL((input_kernel<TI, bf16>), grid, dim3(256), 0, st, (const TI*)x, (bf16*)dst, B, HW); break;
+        case LP_F32: hipLaunchKernelGGL((input_kernel<TI, float>), grid, dim3(256), 0, st, (const TI*)x, (float*)dst, B, HW); break;
+        default: return fail(LP_ERR_ARG, "input: dtype");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("input launch: ") + hipGetErrorString(e));
+    return LP_OK;
+}
+
+int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st) {
+    switch (x_dtype) {
+        case LP_F16: return input_launch_to<f16>(x, dst, dtype, B, H, W, st);
+        case LP_BF16: return input_launch_to<bf16>(x, dst, dtype, B, H, W, st);
+        case LP_F32: return input_launch_to<float>(x, dst, dtype, B, H, W, st);
+    }
+    return fail(LP_ERR_ARG, "input: x dtype");
+}
+
+// ---- SPPF pool chain: y1 = m(x), y2 = m(y1), y3 = m(y2) with m = 5x5 stride-1 pad-2 max pool
+// (yolov6/layers/common.py:144-146).  One block owns (image, 8-channel group): the whole h x w plane of the
+// group lives in LDS and each pool is a separable row pass + column pass (max is exact in every dtype, so
+// separability and the activation dtype do not change results).  Out-of-image taps are skipped, which is
+// what -inf padding does.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
+                                                        T* __restrict__ d3, int h, int w, int cs) {
+    extern __shared__ __attribute__((aligned(16))) char pool_smem[];
+    const int hw = h * w;
+    T* cur = (T*)pool_smem;          // [hw][8]
+    T* tmp = cur + (size_t)hw * 8;   // [hw][8]
+    const int groups = cs / 8;
+    const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
+    const long long base = (long long)b * hw * cs + cg * 8;
+    const int n = hw * 8;
+    for (int i = threadIdx.x; i < n; i += 256) cur[i] = src[base + (long long)(i >> 3) * cs + (i & 7)];
+    __syncthreads();
+    T* outs[3] = {d1, d2, d3};
+    for (int round = 0; round < 3; ++round) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int p = i >> 3, c = i & 7;
+            const int y = p / w, x = p - y * w;
+            const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= w ? w - 1 : x + 2;
+            T m = cur[(y * w + x0) * 8 + c];
+            for (int xx = x0 + 1; xx <= x1; ++xx) {
+                const T v = cur[(y * w + xx) * 8 + c];
+                m = (float)v > (float)m ? v : m;
+            }
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int p = i >> 3, c = i & 7;
+            const int y = p / w, x = p - y * w;
+            const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= h ? h - 1 : y + 2;
+            T m = tmp[(y0 * w + x) * 8 + c];
+            for (int yy = y0 + 1; yy <= y1; ++yy) {
+                const T v = tmp[(yy * w + x) * 8 + c];
+                m = (float)v > (float)m ? v : m;
+            }
+            outs[round][base + (long long)p * cs + c] = m;
+            cur[i] = m;   // element i is only read by its own row pass peers after the barrier below
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, int h, int w, int cs, hipStream_t st) {
+    const size_t lds = (size_t)h * w * 8 * sizeof(T) * 2;
+    if (lds > 128 * 1024) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)pool_chain_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool attr: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((pool_chain_kernel<T>), dim3((unsigned)(B * (cs / 8))), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2,
+                       (T*)d3, h, w, cs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool launch: ") + hipGetErrorString(e));
+    return LP_OK;
+}
+
+int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B, int h, int w, int cs, hipStream_t st) {
+    switch (dtype) {
+        case LP_F16: return pool_launch_t<f16>(src, d1, d2, d3, B, h, w, cs, st);
+        case LP_BF16: return pool_launch_t<bf16>(src, d1, d2, d3, B, h, w, cs, st);
+        case LP_F32: return pool_launch_t<float>(src, d1, d2, d3, B, h, w, cs, st);
+    }
+    return fail(LP_ERR_ARG, "pool: dtype");
+}
+
+}  // namespace lp

@@ -1,0 +1,537 @@
+// Engine: the frozen op graph of one model (built by the python host from folded weights), weight packing
+// for the MFMA conv kernels, arena placement and the launch loop.  Host code only; kernels live in
+// lp_conv.hip / lp_aux.hip / lp_nms.hip.
+#include "lp_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace lp {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+enum OpKind { OP_INPUT = 0, OP_CONV = 1, OP_DECONV = 2, OP_POOL = 3, OP_HEAD_CLS = 4, OP_HEAD_BOX = 5 };
+
+struct Tensor {
+    int c, cs, sl;     // logical channels, stored channels, log2 downscale
+    size_t offset;     // bytes inside the arena (valid after bind)
+    int h, w;
+};
+
+struct Op {
+    int kind = OP_CONV;
+    int nsrc = 0;
+    int src[LP_MAX_SRC] = {-1, -1, -1, -1};
+    int dst = -1, dst2 = -1, dst3 = -1;
+    int ksize = 1, stride = 1, act = 0;
+    int res = -1;
+    float alpha = 0.f;
+    int cout = 0;        // logical output channels
+    int cin = 0;         // logical input channels (sum over sources)
+    int level = 0, reg_bins = 1;
+    std::vector<float> weight, bias, proj;  // host fp32, reference layouts
+    // filled by finalize
+    int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1;
+    int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
+    size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
+    long long w_phase_stride = 0;              // elements
+};
+
+}  // namespace lp
+
+using namespace lp;
+
+struct lp_engine {
+    int dtype = LP_F16;
+    bool finalized = false;
+    int n_levels = 3;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<unsigned char> blob;  // packed weights (host)
+    char* dev_w = nullptr;            // caller-owned device copy
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    int B = 0, H = 0, W = 0, n_anchors = 0;
+    std::vector<int> level_off;       // first pred row of each level
+    std::vector<hipEvent_t> events;
+};
+
+static bool valid_tensor(const lp_engine* e, int id) { return id >= 0 && id < (int)e->tensors.size(); }
+
+extern "C" const char* lp_version(void) { return "yololp-hip 0.1 (gfx950)"; }
+extern "C" const char* lp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
+    if (!out) return fail(LP_ERR_ARG, "lp_engine_create: null out");
+    if (act_dtype != LP_F16 && act_dtype != LP_BF16 && act_dtype != LP_F32) return fail(LP_ERR_ARG, "lp_engine_create: dtype");
+    lp_engine* e = new lp_engine();
+    e->dtype = act_dtype;
+    *out = e;
+    return LP_OK;
+}
+
+extern "C" void lp_engine_destroy(lp_engine* e) {
+    if (!e) return;
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int lp_engine_tensor(lp_engine* e, int channels, int stride_log2) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_tensor: engine is null or frozen");
+    if (channels < 1 || stride_log2 < 0 || stride_log2 > 6) return fail(LP_ERR_ARG, "lp_engine_tensor: bad shape");
+    Tensor t;
+    t.c = channels;
+    t.cs = round_up(channels, 8);
+    t.sl = stride_log2;
+    t.offset = 0;
+    t.h = t.w = 0;
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+}
+
+extern "C" int lp_engine_add_input(lp_engine* e, int dst) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_input: engine is null or frozen");
+    if (!e->ops.empty()) return fail(LP_ERR_STATE, "lp_engine_add_input: must be the first op");
+    if (!valid_tensor(e, dst) || e->tensors[dst].c != 3 || e->tensors[dst].sl != 0)
+        return fail(LP_ERR_ARG, "lp_engine_add_input: dst must be a 3-channel full-resolution tensor");
+    Op op;
+    op.kind = OP_INPUT;
+    op.dst = dst;
+    op.cout = 3;
+    op.cin = 3;
+    e->ops.push_back(op);
+    return LP_OK;
+}
+
+extern "C" int lp_engine_add_conv(lp_engine* e, const lp_conv_desc* d) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_conv: engine is null or frozen");
+    if (!d || !d->weight || !d->bias) return fail(LP_ERR_ARG, "lp_engine_add_conv: null descriptor / weights");
+    if (d->n_src < 1 || d->n_src > LP_MAX_SRC) return fail(LP_ERR_ARG, "lp_engine_add_conv: n_src");
+    if (!((d->ksize == 1 && d->stride == 1) || (d->ksize == 3 && (d->stride == 1 || d->stride == 2))))
+        return fail(LP_ERR_UNSUPPORTED, "lp_engine_add_conv: only 1x1/s1, 3x3/s1 and 3x3/s2");
+    if (d->act < LP_ACT_NONE || d->act > LP_ACT_SILU) return fail(LP_ERR_ARG, "lp_engine_add_conv: act");
+    if (!valid_tensor(e, d->dst)) return fail(LP_ERR_ARG, "lp_engine_add_conv: dst");
+    Op op;
+    op.kind = OP_CONV;
+    op.nsrc = d->n_src;
+    int cin = 0;
+    if (!valid_tensor(e, d->src[0])) return fail(LP_ERR_ARG, "lp_engine_add_conv: src");
+    const int sl = e->tensors[d->src[0]].sl;
+    for (int i = 0; i < d->n_src; ++i) {
+        if (!valid_tensor(e, d->src[i])) return fail(LP_ERR_ARG, "lp_engine_add_conv: src");
+        if (e->tensors[d->src[i]].sl != sl) return fail(LP_ERR_ARG, "lp_engine_add_conv: sources differ in resolution");
+        if (d->src[i] == d->dst) return fail(LP_ERR_ARG, "lp_engine_add_conv: in-place conv");
+        op.src[i] = d->src[i];
+        cin += e->tensors[d->src[i]].c;
+    }
+    const Tensor& td = e->tensors[d->dst];
+    if (td.sl != sl + (d->stride == 2 ? 1 : 0)) return fail(LP_ERR_ARG, "lp_engine_add_conv: dst resolution");
+    if (d->res >= 0) {
+        if (!valid_tensor(e, d->res) || e->tensors[d->res].c != td.c || e->tensors[d->res].sl != td.sl || d->res == d->dst)
+            return fail(LP_ERR_ARG, "lp_engine_add_conv: residual shape");
+    }
+    op.dst = d->dst;
+    op.ksize = d->ksize;
+    op.stride = d->stride;
+    op.act = d->act;
+    op.res = d->res >= 0 ? d->res : -1;
+    op.alpha = d->res_alpha;
+    op.cout = td.c;
+    op.cin = cin;
+    op.weight.assign(d->weight, d->weight + (size_t)op.cout * cin * d->ksize * d->ksize);
+    op.bias.assign(d->bias, d->bias + op.cout);
+    e->ops.push_back(op);
+    return LP_OK;
+}
+
+extern "C" int lp_engine_add_deconv2x2(lp_engine* e, int src, int dst, const float* weight, const float* bias) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_deconv2x2: engine is null or frozen");
+    if (!weight || !bias || !valid_tensor(e, src) || !valid_tensor(e, dst) || src == dst)
+        return fail(LP_ERR_ARG, "lp_engine_add_deconv2x2: bad argument");
+    if (e->tensors[dst].sl != e->tensors[src].sl - 1) return fail(LP_ERR_ARG, "lp_engine_add_deconv2x2: dst must be 2x the source");
+    Op op;
+    op.kind = OP_DECONV;
+    op.nsrc = 1;
+    op.src[0] = src;
+    op.dst = dst;
+    op.cin = e->tensors[src].c;
+    op.cout = e->tensors[dst].c;
+    op.weight.assign(weight, weight + (size_t)op.cin * op.cout * 4);
+    op.bias.assign(bias, bias + op.cout);
+    e->ops.push_back(op);
+    return LP_OK;
+}
+
+extern "C" int lp_engine_add_pool5_chain(lp_engine* e, int src, int dst1, int dst2, int dst3) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_pool5_chain: engine is null or frozen");
+    const int ids[4] = {src, dst1, dst2, dst3};
+    for (int i = 0; i < 4; ++i) {
+        if (!valid_tensor(e, ids[i])) return fail(LP_ERR_ARG, "lp_engine_add_pool5_chain: tensor id");
+        if (e->tensors[ids[i]].c != e->tensors[src].c || e->tensors[ids[i]].sl != e->tensors[src].sl)
+            return fail(LP_ERR_ARG, "lp_engine_add_pool5_chain: shapes differ");
+        for (int k = 0; k < i; ++k)
+            if (ids[k] == ids[i]) return fail(LP_ERR_ARG, "lp_engine_add_pool5_chain: tensors must be distinct");
+    }
+    Op op;
+    op.kind = OP_POOL;
+    op.nsrc = 1;
+    op.src[0] = src;
+    op.dst = dst1;
+    op.dst2 = dst2;
+    op.dst3 = dst3;
+    op.cin = op.cout = e->tensors[src].c;
+    e->ops.push_back(op);
+    return LP_OK;
+}
+
+static int add_head(lp_engine* e, int kind, int src, int level, int cout, int reg_bins, const float* weight, const float* bias,
+                    const float* proj) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_head: engine is null or frozen");
+    if (!weight || !bias || !valid_tensor(e, src) || level < 0 || level > 3 || cout < 1)
+        return fail(LP_ERR_ARG, "lp_engine_add_head: bad argument");
+    if (e->tensors[src].sl != 3 + level) return fail(LP_ERR_ARG, "lp_engine_add_head: level / resolution mismatch (strides 8,16,32,64)");
+    Op op;
+    op.kind = kind;
+    op.nsrc = 1;
+    op.src[0] = src;
+    op.level = level;
+    op.reg_bins = reg_bins;
+    op.cin = e->tensors[src].c;
+    op.cout = cout;
+    op.weight.assign(weight, weight + (size_t)cout * op.cin);
+    op.bias.assign(bias, bias + cout);
+    if (proj) op.proj.assign(proj, proj + reg_bins);
+    e->ops.push_back(op);
+    return LP_OK;
+}
+
+extern "C" int lp_engine_add_head_cls(lp_engine* e, int src, int level, int n_cls, const float* weight, const float* bias) {
+    if (n_cls != LP_PRED_COLS - 13) return fail(LP_ERR_ARG, "lp_engine_add_head_cls: n_cls must be 277 (31+24+6*37)");
+    return add_head(e, OP_HEAD_CLS, src, level, n_cls, 1, weight, bias, nullptr);
+}
+
+extern "C" int lp_engine_add_head_box(lp_engine* e, int src, int level, int reg_bins, const float* weight, const float* bias,
+                                      const float* proj) {
+    if (reg_bins < 1 || 4 * reg_bins + 8 > 128) return fail(LP_ERR_ARG, "lp_engine_add_head_box: reg_bins");
+    if (reg_bins > 1 && !proj) return fail(LP_ERR_ARG, "lp_engine_add_head_box: DFL needs proj");
+    return add_head(e, OP_HEAD_BOX, src, level, 4 * reg_bins + 8, reg_bins, weight, bias, proj);
+}
+
+// ---- weight packing -------------------------------------------------------------------------------------
+static void put_elem(unsigned char* dst, size_t idx, float v, int dtype) {
+    if (dtype == LP_F32) {
+        memcpy(dst + idx * 4, &v, 4);
+    } else if (dtype == LP_F16) {
+        const f16 h = (f16)v;      // round-to-nearest-even, like torch's .half()
+        memcpy(dst + idx * 2, &h, 2);
+    } else {
+        const bf16 h = (bf16)v;
+        memcpy(dst + idx * 2, &h, 2);
+    }
+}
+
+static int pick_cfg(int dtype, int ksize, int stride, int cout_store) {
+    int best = CFG_A;
+    long best_pad = -1;
+    const int cfgs[3] = {CFG_A, CFG_B, CFG_C};  // larger cout tile first: wins ties
+    for (int k = 0; k < 3; ++k) {
+        const ConvShape s = conv_shape(dtype, cfgs[k], ksize, stride);
+        const long pad = (long)ceil_div(cout_store, s.CB) * s.CB;
+        if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = cfgs[k]; }
+    }
+    return best;
+}
+
+extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_finalize: engine is null or already frozen");
+    if (e->ops.empty() || e->ops[0].kind != OP_INPUT) return fail(LP_ERR_STATE, "lp_engine_finalize: first op must be the input");
+    if (n_levels < 1 || n_levels > 4) return fail(LP_ERR_ARG, "lp_engine_finalize: n_levels");
+    e->n_levels = n_levels;
+    const int dt = e->dtype;
+    const size_t esz = dtype_size(dt);
+    std::vector<unsigned char>& blob = e->blob;
+    blob.clear();
+    auto align = [&]() { blob.resize((blob.size() + 255) / 256 * 256, 0); };
+    for (Op& op : e->ops) {
+        if (op.kind == OP_INPUT || op.kind == OP_POOL) continue;
+        const int ks = op.kind == OP_CONV ? op.ksize : 1;
+        const int st = op.kind == OP_CONV ? op.stride : 1;
+        int cout_store;
+        if (op.kind == OP_HEAD_CLS) { op.mode = MODE_PRED; op.cfg = CFG_B; cout_store = op.cout; }
+        else if (op.kind == OP_HEAD_BOX) { op.mode = MODE_DECODE; op.cfg = CFG_A; cout_store = op.cout; }
+        else { op.mode = MODE_ACT; cout_store = e->tensors[op.dst].cs; op.cfg = pick_cfg(dt, ks, st, cout_store); }
+        const ConvShape s = conv_shape(dt, op.cfg, ks, st);
+        op.nct = ceil_div(cout_store, s.CB);
+        op.nphase = op.kind == OP_DECONV ? 4 : 1;
+        // K-chunks: every source starts a new chunk, so a chunk never straddles two tensors
+        int cin_off[LP_MAX_SRC + 1] = {0};
+        op.chunk_begin[0] = 0;
+        for (int i = 0; i < op.nsrc; ++i) {
+            const Tensor& t = e->tensors[op.src[i]];
+            op.chunk_begin[i + 1] = op.chunk_begin[i] + ceil_div(t.cs, s.KC);
+            cin_off[i + 1] = cin_off[i] + t.c;
+        }
+        for (int i = op.nsrc; i < LP_MAX_SRC; ++i) op.chunk_begin[i + 1] = op.chunk_begin[op.nsrc];
+        op.nchunks = op.chunk_begin[op.nsrc];
+        const int taps = ks * ks;
+        const size_t per_phase = (size_t)op.nct * op.nchunks * taps * s.CB * s.KC;
+        op.w_phase_stride = (long long)per_phase;
+        align();
+        op.w_off = blob.size();
+        blob.resize(blob.size() + per_phase * op.nphase * esz, 0);
+        unsigned char* wp = blob.data() + op.w_off;
+        for (int ph = 0; ph < op.nphase; ++ph)
+            for (int ct = 0; ct < op.nct; ++ct)
+                for (int i = 0; i < op.nsrc; ++i) {
+                    const Tensor& t = e->tensors[op.src[i]];
+                    for (int q = op.chunk_begin[i]; q < op.chunk_begin[i + 1]; ++q) {
+                        const int c0 = (q - op.chunk_begin[i]) * s.KC;
+                        for (int tp = 0; tp < taps; ++tp)
+                            for (int cl = 0; cl < s.CB; ++cl) {
+                                const int co = ct * s.CB + cl;
+                                if (co >= op.cout) continue;
+                                const size_t row = ((((size_t)ph * op.nct + ct) * op.nchunks + q) * taps + tp) * s.CB + cl;
+                                for (int kc = 0; kc < s.KC; ++kc) {
+                                    const int c = c0 + kc;
+                                    if (c >= t.c) break;
+                                    const int ci = cin_off[i] + c;
+                                    float v;
+                                    if (op.kind == OP_DECONV)  // ConvTranspose2d weight [Cin][Cout][2][2], phase = dy*2+dx
+                                        v = op.weight[((size_t)ci * op.cout + co) * 4 + ph];
+                                    else                        // Conv2d weight [Cout][Cin][k][k]
+                                        v = op.weight[((size_t)co * op.cin + ci) * taps + tp];
+                                    put_elem(wp, row * s.KC + kc, v, dt);
+                                }
+                            }
+                    }
+                }
+        align();
+        op.b_off = blob.size();
+        blob.resize(blob.size() + (size_t)op.nct * s.CB * 4, 0);
+        memcpy(blob.data() + op.b_off, op.bias.data(), (size_t)op.cout * 4);
+        if (!op.proj.empty()) {
+            align();
+            op.proj_off = blob.size();
+            blob.resize(blob.size() + op.proj.size() * 4, 0);
+            memcpy(blob.data() + op.proj_off, op.proj.data(), op.proj.size() * 4);
+        }
+        std::vector<float>().swap(op.weight);  // the fp32 originals are no longer needed
+    }
+    align();
+    e->finalized = true;
+    return LP_OK;
+}
+
+extern "C" size_t lp_engine_weight_bytes(const lp_engine* e) { return e && e->finalized ? e->blob.size() : 0; }
+
+extern "C" int lp_engine_upload(lp_engine* e, void* dev_weights, void* stream) {
+    if (!e || !e->finalized) return fail(LP_ERR_STATE, "lp_engine_upload: finalize first");
+    if (!dev_weights || ((uintptr_t)dev_weights & 255)) return fail(LP_ERR_ARG, "lp_engine_upload: need a 256-byte aligned device pointer");
+    LP_HIP_CHECK(hipMemcpyAsync(dev_weights, e->blob.data(), e->blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+    LP_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    e->dev_w = (char*)dev_weights;
+    return LP_OK;
+}
+
+// ---- arena ----------------------------------------------------------------------------------------------
+static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>* out) {
+    size_t off = 0;
+    const size_t esz = dtype_size(e->dtype);
+    for (size_t i = 0; i < e->tensors.size(); ++i) {
+        Tensor t = e->tensors[i];
+        t.h = H >> t.sl;
+        t.w = W >> t.sl;
+        t.offset = off;
+        off += ((size_t)B * t.h * t.w * t.cs * esz + 255) / 256 * 256;
+        if (out) (*out)[i] = t;
+    }
+    return off + 256;
+}
+
+extern "C" size_t lp_engine_arena_bytes(const lp_engine* e, int B, int H, int W) {
+    if (!e || B < 1 || H < 32 || W < 32 || (H & 31) || (W & 31)) return 0;
+    return place(e, B, H, W, nullptr);
+}
+
+extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B, int H, int W) {
+    if (!e || !e->finalized) return fail(LP_ERR_STATE, "lp_engine_bind: finalize first");
+    if (B < 1 || H < 32 || W < 32 || (H & 31) || (W & 31)) return fail(LP_ERR_ARG, "lp_engine_bind: H and W must be positive multiples of 32");
+    if (!dev_arena || ((uintptr_t)dev_arena & 255)) return fail(LP_ERR_ARG, "lp_engine_bind: need a 256-byte aligned device pointer");
+    const size_t need = place(e, B, H, W, nullptr);
+    if (bytes < need) return fail(LP_ERR_ARG, "lp_engine_bind: arena too small");
+    if ((long long)B * H * W >= (1LL << 31)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_bind: batch too large for 32-bit pixel indices");
+    place(e, B, H, W, &e->tensors);
+    e->arena = (char*)dev_arena;
+    e->arena_bytes = bytes;
+    e->B = B;
+    e->H = H;
+    e->W = W;
+    e->level_off.assign(e->n_levels + 1, 0);
+    for (int l = 0; l < e->n_levels; ++l) e->level_off[l + 1] = e->level_off[l] + (H >> (3 + l)) * (W >> (3 + l));
+    e->n_anchors = e->level_off[e->n_levels];
+    return LP_OK;
+}
+
+extern "C" int lp_engine_tensor_info(const lp_engine* e, int id, size_t* offset, int* c, int* c_stored, int* h, int* w) {
+    if (!e || !valid_tensor(e, id)) return fail(LP_ERR_ARG, "lp_engine_tensor_info: tensor id");
+    const Tensor& t = e->tensors[id];
+    if (offset) *offset = t.offset;
+    if (c) *c = t.c;
+    if (c_stored) *c_stored = t.cs;
+    if (h) *h = t.h;
+    if (w) *w = t.w;
+    return LP_OK;
+}
+
+extern "C" int lp_engine_num_anchors(const lp_engine* e) { return e ? e->n_anchors : 0; }
+extern "C" int lp_engine_num_ops(const lp_engine* e) { return e ? (int)e->ops.size() : 0; }
+
+extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksize, int* cin, int* cout, double* flops, double* bytes) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_info: op index");
+    if (!e->arena) return fail(LP_ERR_STATE, "lp_engine_op_info: bind first");
+    const Op& op = e->ops[i];
+    const double esz = (double)dtype_size(e->dtype);
+    double fl = 0, by = 0;
+    auto tbytes = [&](int id) { const Tensor& t = e->tensors[id]; return (double)e->B * t.h * t.w * t.c * esz; };
+    const Tensor& s0 = e->tensors[op.kind == OP_INPUT ? op.dst : op.src[0]];
+    const double in_px = (double)e->B * s0.h * s0.w;
+    switch (op.kind) {
+        case OP_INPUT: by = in_px * 3 * 4 + tbytes(op.dst); break;
+        case OP_CONV: {
+            const Tensor& d = e->tensors[op.dst];
+            fl = 2.0 * e->B * d.h * d.w * op.cout * op.cin * op.ksize * op.ksize;
+            for (int k = 0; k < op.nsrc; ++k) by += tbytes(op.src[k]);
+            by += tbytes(op.dst) + (op.res >= 0 ? tbytes(op.res) : 0) + (double)op.cout * op.cin * op.ksize * op.ksize * esz;
+            break;
+        }
+        case OP_DECONV: fl = 2.0 * in_px * op.cin * op.cout * 4; by = tbytes(op.src[0]) + tbytes(op.dst) + 4.0 * op.cin * op.cout * esz; break;
+        case OP_POOL: by = 4 * tbytes(op.src[0]); break;
+        case OP_HEAD_CLS:
+        case OP_HEAD_BOX:
+            fl = 2.0 * in_px * op.cin * op.cout;
+            by = tbytes(op.src[0]) + in_px * (op.kind == OP_HEAD_CLS ? op.cout : 13) * 4 + (double)op.cin * op.cout * esz;
+            break;
+    }
+    if (kind) *kind = op.kind;
+    if (ksize) *ksize = op.ksize;
+    if (cin) *cin = op.cin;
+    if (cout) *cout = op.cout;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return LP_OK;
+}
+
+// ---- execution ------------------------------------------------------------------------------------------
+static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float* pred, hipStream_t st) {
+    const int dt = e->dtype;
+    auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
+    if (op.kind == OP_INPUT) return input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
+    if (op.kind == OP_POOL) {
+        const Tensor& t = e->tensors[op.src[0]];
+        return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
+    }
+    const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
+    const ConvShape s = conv_shape(dt, op.cfg, ks, stv);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = op.nsrc;
+    for (int i = 0; i < op.nsrc; ++i) { a.src[i].ptr = tptr(op.src[i]); a.src[i].cs = e->tensors[op.src[i]].cs; }
+    for (int i = 0; i <= LP_MAX_SRC; ++i) a.chunk_begin[i] = op.chunk_begin[i];
+    a.w = e->dev_w + op.w_off;
+    a.bias = (const float*)(e->dev_w + op.b_off);
+    const Tensor& s0 = e->tensors[op.src[0]];
+    a.B = e->B;
+    a.H = s0.h;
+    a.W = s0.w;
+    a.Ho = stv == 2 ? s0.h / 2 : s0.h;
+    a.Wo = stv == 2 ? s0.w / 2 : s0.w;
+    conv_pick_tile(s, ks, stv, a.Ho, a.Wo, &a.TH, &a.TW);
+    a.tiles_x = ceil_div(a.Wo, a.TW);
+    a.tiles_y = ceil_div(a.Ho, a.TH);
+    a.nct = op.nct;
+    a.nphase = op.nphase;
+    a.w_phase_stride = op.w_phase_stride;
+    a.out_scale = op.kind == OP_DECONV ? 2 : 1;
+    a.act = op.act;
+    a.alpha = op.alpha;
+    if (op.mode == MODE_ACT) {
+        const Tensor& d = e->tensors[op.dst];
+        a.out = tptr(op.dst);
+        a.out_c = d.cs;
+        a.out_pix_stride = d.cs;
+        a.out_img_stride = (long long)d.h * d.w * d.cs;
+        if (op.res >= 0) { a.res = tptr(op.res); a.res_cs = e->tensors[op.res].cs; }
+    } else {
+        if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
+        const long long row0 = e->level_off[op.level];
+        a.out_pix_stride = LP_PRED_COLS;
+        a.out_img_stride = (long long)e->n_anchors * LP_PRED_COLS;
+        if (op.mode == MODE_PRED) {
+            a.out = pred + row0 * LP_PRED_COLS + 13;
+            a.out_c = op.cout;
+        } else {
+            a.out = pred + row0 * LP_PRED_COLS;
+            a.out_c = op.cout;
+            a.reg_bins = op.reg_bins;
+            a.proj = op.proj.empty() ? nullptr : (const float*)(e->dev_w + op.proj_off);
+            a.stride_px = (float)(8 << op.level);
+        }
+    }
+    return conv_launch(dt, op.cfg, op.mode, ks, stv, a, st);
+}
+
+static int check_ready(const lp_engine* e, const void* x, int x_dtype) {
+    if (!e || !e->finalized) return fail(LP_ERR_STATE, "forward: engine not finalized");
+    if (!e->dev_w) return fail(LP_ERR_STATE, "forward: weights not uploaded");
+    if (!e->arena) return fail(LP_ERR_STATE, "forward: arena not bound");
+    if (!x) return fail(LP_ERR_ARG, "forward: x is null");
+    if (x_dtype != LP_F16 && x_dtype != LP_BF16 && x_dtype != LP_F32) return fail(LP_ERR_ARG, "forward: x dtype");
+    return LP_OK;
+}
+
+extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    for (const Op& op : e->ops) {
+        rc = run_op(e, op, x, x_dtype, pred, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return LP_OK;
+}
+
+extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    if (!op_ms || reps < 1) return fail(LP_ERR_ARG, "profile: op_ms / reps");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = e->ops.size();
+    while (e->events.size() < n + 1) {
+        hipEvent_t ev;
+        LP_HIP_CHECK(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
+    rc = lp_engine_forward(e, x, x_dtype, pred, stream);  // untimed warm run
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) op_ms[i] = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        LP_HIP_CHECK(hipEventRecord(e->events[0], st));
+        for (size_t i = 0; i < n; ++i) {
+            rc = run_op(e, e->ops[i], x, x_dtype, pred, st);
+            if (rc) return rc;
+            LP_HIP_CHECK(hipEventRecord(e->events[i + 1], st));
+        }
+        LP_HIP_CHECK(hipEventSynchronize(e->events[n]));
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            LP_HIP_CHECK(hipEventElapsedTime(&ms, e->events[i], e->events[i + 1]));
+            op_ms[i] += ms / reps;
+        }
+    }
+    return LP_OK;
+}

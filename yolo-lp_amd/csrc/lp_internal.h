@@ -1,0 +1,77 @@
+// Internal declarations shared by the translation units of libyololp_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "../../include/lp_hip.h"
+
+namespace lp {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+#define LP_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::lp::fail(LP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+inline size_t dtype_size(int dt) { return dt == LP_F32 ? 4 : 2; }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- conv launch description ----------------------------------------------------------------------
+enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
+enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/ };
+
+struct ConvSrc {
+    const void* ptr;
+    int cs;  // stored channels (multiple of 8) = pixel stride in elements
+};
+
+struct ConvArgs {
+    ConvSrc src[LP_MAX_SRC];
+    int chunk_begin[LP_MAX_SRC + 1];  // prefix sums of K-chunks per source
+    int nsrc;
+    const void* w;          // packed [phase][cout_tile][chunk][tap][CB][KC]
+    const float* bias;      // [phase?][nct*CB]  (same for every phase)
+    void* out;
+    const void* res;        // residual (same dtype/geometry as out) or null
+    int res_cs;
+    float alpha;
+    int B, H, W;            // input spatial dims
+    int Ho, Wo;             // conv output dims (before out_scale)
+    int TH, TW, tiles_x, tiles_y;
+    int nct;                // cout tiles
+    int out_c;              // channels to store (multiple of the 16-B granule for MODE_ACT)
+    long long out_img_stride;  // elements
+    int out_pix_stride;        // elements
+    int out_scale;          // 1, or 2 for the transposed conv (phase p writes (2y + p/2, 2x + p%2))
+    int nphase;
+    long long w_phase_stride;  // elements
+    int act;
+    // MODE_DECODE
+    int reg_bins;
+    const float* proj;
+    float stride_px;
+};
+
+struct ConvShape {  // compile-time geometry of one kernel configuration, mirrored on the host
+    int CB, PB, KC, HPMAX, NT;
+};
+ConvShape conv_shape(int dtype, int cfg, int ksize, int stride);
+// Picks the output tile (TH x TW <= PB output pixels, halo <= HPMAX) that needs the fewest blocks.
+void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW);
+int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st);
+
+// ---- auxiliary kernels ----------------------------------------------------------------------------
+int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
+int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B, int h, int w, int cs, hipStream_t st);
+
+}  // namespace lp

@@ -1,0 +1,315 @@
+// Post-processing of the LP head output on gfx950: score / arg-max wavefront reductions, candidate
+// collection, stable descending sort and greedy IoU suppression, for the whole batch in four launches and
+// without any device->host synchronisation.
+//
+// Reference semantics (bit-exact selection is the bar): yolov6/utils/nms.py:68-125 and the CPU kernel of
+// torchvision.ops.nms it calls (:121).  Everything is fp32, evaluated op by op in the reference's order
+// (this file is compiled with -ffp-contract=off; `/` is the correctly rounded division):
+//   x[:,13:] *= x[:,4:5]                              in place (written back only where obj != 1)
+//   box = (cx - w/2, cy - h/2, cx + w/2, cy + h/2)
+//   8 x (max, FIRST arg-max) over column groups [13,44) [44,68) [68,105) ... [253,290)
+//   keep-mask: (pro+alp+ad0+ad1+ad2+ad3+ad4+ad4)/8 >= fp32(conf)     (ad4 twice, ad5 omitted: reference quirk)
+//   score:     (pro+alp+ad0+ad1+ad2+ad3+ad4+ad5)/8                   (left-to-right sums)
+//   order: descending score, ties by ascending anchor index (stable sort); at most 30000 candidates
+//   greedy: keep i, suppress later j with inter/(area_i+area_j-inter) > iou (double compare), until max_det
+#include "lp_internal.h"
+
+namespace lp {
+
+static constexpr int NCOL = LP_PRED_COLS;
+static constexpr int NDET = LP_DET_COLS;
+static constexpr int MAX_NMS = 30000;
+static constexpr int SORT_LDS_KEYS = 8192;   // keys sorted inside LDS (64 KiB); larger lists are sorted in global memory
+__constant__ int c_seg[9] = {13, 44, 68, 105, 142, 179, 216, 253, 290};
+
+struct NmsWs {  // carve-up of the caller's workspace
+    int32_t* cnt;            // [B]
+    unsigned long long* keys;  // [B][NP]
+    float* rows;             // [B][N][28]
+    float4* sbox;            // [B][N]
+    int32_t* kept;           // [B][N]
+    int NP;
+    size_t bytes;
+};
+
+static int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+static NmsWs carve(void* base, int B, int N) {
+    NmsWs w;
+    w.NP = next_pow2(N < 64 ? 64 : N);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return (char*)base + o;
+    };
+    w.cnt = (int32_t*)take((size_t)B * 4);
+    w.keys = (unsigned long long*)take((size_t)B * w.NP * 8);
+    w.rows = (float*)take((size_t)B * N * NDET * 4);
+    w.sbox = (float4*)take((size_t)B * N * 16);
+    w.kept = (int32_t*)take((size_t)B * N * 4);
+    w.bytes = off;
+    return w;
+}
+
+// (value, index) max with torch.max's tie rule: the smaller index wins among equal values.
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+// One wave per anchor row; a block of 4 waves walks rows with a grid stride.
+__global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, int B, int N, float conf_f,
+                                                   float* __restrict__ rows, unsigned long long* __restrict__ keys,
+                                                   int32_t* __restrict__ cnt, int NP) {
+    const int lane = threadIdx.x & 63;
+    const long long nrows = (long long)B * N;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long wstride = (long long)gridDim.x * 4;
+    for (long long row = wave0; row < nrows; row += wstride) {
+        float* x = pred + row * NCOL;
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            v[k] = c < NCOL ? x[c] : 0.f;
+        }
+        const float obj = __shfl(v[0], 4);
+        // conf = obj_conf * cls_conf, in place (nms.py:76); obj == 1 leaves the bits unchanged: no store needed
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = lane + 64 * k;
+            if (c >= 13 && c < NCOL) {
+                v[k] = v[k] * obj;
+                if (obj != 1.0f) x[c] = v[k];
+            }
+        }
+        float cf[8];
+        int ci[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int a = c_seg[s], b = c_seg[s + 1];
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = lane + 64 * k;
+                if (c >= a && c < b) { bv = v[k]; bi = c - a; }  // a lane owns at most one column of a group (< 64 wide)
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                argmax_combine(bv, bi, ov, oi);
+            }
+            cf[s] = bv;
+            ci[s] = bi;
+        }
+        float m = cf[0] + cf[1]; m = m + cf[2]; m = m + cf[3]; m = m + cf[4]; m = m + cf[5];
+        m = m + cf[6]; m = m + cf[6]; m = m / 8.0f;
+        if (!(m >= conf_f)) continue;   // wave-uniform
+        float sc = cf[0] + cf[1]; sc = sc + cf[2]; sc = sc + cf[3]; sc = sc + cf[4]; sc = sc + cf[5];
+        sc = sc + cf[6]; sc = sc + cf[7]; sc = sc / 8.0f;
+
+        const float cx = __shfl(v[0], 0), cy = __shfl(v[0], 1), bw = __shfl(v[0], 2), bh = __shfl(v[0], 3);
+        const float corner = __shfl(v[0], (lane + 1) & 63);   // lanes 4..11 pick columns 5..12
+        float o;
+        if (lane == 0) o = cx - bw / 2;
+        else if (lane == 1) o = cy - bh / 2;
+        else if (lane == 2) o = cx + bw / 2;
+        else if (lane == 3) o = cy + bh / 2;
+        else if (lane < 12) o = corner;
+        else {
+            const int s = (lane - 12) & 7;
+            float fv = cf[0];
+            int iv = ci[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (s == k) { fv = cf[k]; iv = ci[k]; }
+            o = lane < 20 ? fv : (float)iv;
+        }
+        const int b = (int)(row / N), n = (int)(row - (long long)b * N);
+        if (lane < NDET) rows[row * NDET + lane] = o;
+        if (lane == 0) {
+            unsigned u = __float_as_uint(sc);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable bits
+            const unsigned long long key = ((unsigned long long)(~u) << 32) | (unsigned)n;  // ascending key = descending score, then index
+            const int pos = atomicAdd(&cnt[b], 1);
+            keys[(long long)b * NP + pos] = key;
+        }
+    }
+}
+
+// One block per image: ascending bitonic sort of its candidate keys (all keys are distinct, so the result is
+// unique whatever order the atomics appended them in).
+__global__ __launch_bounds__(1024) void sort_kernel(unsigned long long* __restrict__ keys, const int32_t* __restrict__ cnt, int NP) {
+    __shared__ unsigned long long skeys[SORT_LDS_KEYS];
+    const int b = blockIdx.x;
+    const int nc = cnt[b];
+    if (nc <= 1) return;
+    int n = 64;
+    while (n < nc) n <<= 1;
+    unsigned long long* g = keys + (long long)b * NP;
+    const bool in_lds = n <= SORT_LDS_KEYS;
+    unsigned long long* d = in_lds ? skeys : g;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const unsigned long long k = i < nc ? g[i] : ~0ull;
+        d[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = d[i], c = d[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { d[i] = c; d[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds)
+        for (int i = threadIdx.x; i < nc; i += 1024) g[i] = d[i];
+}
+
+__device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1, float jy1,
+                                      float jx2, float jy2, float thr_f) {
+    const float xx1 = ix1 > jx1 ? ix1 : jx1;
+    const float yy1 = iy1 > jy1 ? iy1 : jy1;
+    const float xx2 = ix2 < jx2 ? ix2 : jx2;
+    const float yy2 = iy2 < jy2 ? iy2 : jy2;
+    float w = xx2 - xx1;
+    if (!(w > 0.f)) w = 0.f;
+    float h = yy2 - yy1;
+    if (!(h > 0.f)) h = 0.f;
+    const float inter = w * h;
+    const float jarea = (jx2 - jx1) * (jy2 - jy1);
+    const float ovr = inter / (iarea + jarea - inter);
+    return ovr > thr_f;   // thr_f = largest fp32 <= the double threshold  <=>  (double)ovr > iou_thres
+}
+
+// One block per image: greedy suppression over the sorted candidates, 64 at a time.  Wave 0 resolves the
+// dependencies inside a chunk with ballots; then every thread strikes out the later candidates that overlap
+// one of the chunk's survivors.  Ends with the gather of the kept rows into det.
+static constexpr int NMS_T = 512;
+__global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ rows,
+                                                      float4* __restrict__ sbox, int32_t* __restrict__ kept,
+                                                      const int32_t* __restrict__ cnt, int N, int NP, float thr_f, int max_det,
+                                                      float* __restrict__ det, int32_t* __restrict__ count,
+                                                      int32_t* __restrict__ keep_out) {
+    __shared__ unsigned sup[(MAX_NMS + 31) / 32 + 1];
+    __shared__ float ck[64][5];
+    __shared__ int s_nk, s_total;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int nc = cnt[b];
+    if (nc > MAX_NMS) nc = MAX_NMS;
+    const unsigned long long* kb = keys + (long long)b * NP;
+    const float* rb = rows + (long long)b * N * NDET;
+    float4* sb = sbox + (long long)b * N;
+    int32_t* kp = kept + (long long)b * N;
+    for (int i = tid; i < (nc + 31) / 32 + 1; i += NMS_T) sup[i] = 0;
+    for (int i = tid; i < nc; i += NMS_T) {
+        const int idx = (int)(kb[i] & 0xffffffffu);
+        sb[i] = *(const float4*)(rb + (long long)idx * NDET);   // rows are 112 B apart: 16-B aligned
+    }
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+
+    const int nchunk = (nc + 63) / 64;
+    for (int c = 0; c < nchunk; ++c) {
+        if (tid < 64) {
+            const int i = c * 64 + tid;
+            const bool valid = i < nc;
+            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) bx = sb[i];
+            const float area = (bx.z - bx.x) * (bx.w - bx.y);
+            bool alive = valid && !((sup[i >> 5] >> (i & 31)) & 1u);
+            unsigned long long todo = __ballot(alive);
+            unsigned long long keptmask = 0;
+            while (todo) {
+                const int k = __ffsll((long long)todo) - 1;
+                keptmask |= 1ull << k;
+                todo &= ~(1ull << k);
+                const float kx1 = __shfl(bx.x, k), ky1 = __shfl(bx.y, k), kx2 = __shfl(bx.z, k), ky2 = __shfl(bx.w, k);
+                const float karea = __shfl(area, k);
+                if (alive && tid > k && iou_gt(kx1, ky1, kx2, ky2, karea, bx.x, bx.y, bx.z, bx.w, thr_f)) alive = false;
+                todo &= __ballot(alive);
+            }
+            const int total = s_total;
+            if ((keptmask >> tid) & 1ull) {
+                const int rank = __popcll(keptmask & ((1ull << tid) - 1ull));
+                ck[rank][0] = bx.x; ck[rank][1] = bx.y; ck[rank][2] = bx.z; ck[rank][3] = bx.w; ck[rank][4] = area;
+                kp[total + rank] = (int)(kb[i] & 0xffffffffu);
+            }
+            if (tid == 0) { s_nk = __popcll(keptmask); }
+        }
+        __syncthreads();
+        const int nk = s_nk;
+        const int total_after = s_total + nk;
+        __syncthreads();                       // everyone has read s_total before it is updated
+        if (tid == 0) s_total = total_after;
+        if (total_after >= max_det) break;     // block-uniform
+        for (int jj = (c + 1) * 64 + tid; jj < nc; jj += NMS_T) {
+            if ((sup[jj >> 5] >> (jj & 31)) & 1u) continue;
+            const float4 bj = sb[jj];
+            for (int k = 0; k < nk; ++k) {
+                if (iou_gt(ck[k][0], ck[k][1], ck[k][2], ck[k][3], ck[k][4], bj.x, bj.y, bj.z, bj.w, thr_f)) {
+                    atomicOr(&sup[jj >> 5], 1u << (jj & 31));
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    int total = s_total;
+    if (total > max_det) total = max_det;
+    if (tid == 0) count[b] = total;
+    float* db = det + (long long)b * max_det * NDET;
+    for (int i = tid; i < max_det * NDET; i += NMS_T) {
+        const int k = i / NDET, col = i - k * NDET;
+        db[i] = k < total ? rb[(long long)kp[k] * NDET + col] : 0.f;
+    }
+    if (keep_out)
+        for (int k = tid; k < max_det; k += NMS_T) keep_out[(long long)b * max_det + k] = k < total ? kp[k] : -1;
+}
+
+}  // namespace lp
+
+using namespace lp;
+
+extern "C" size_t lp_nms_workspace_bytes(int B, int N) {
+    if (B < 1 || N < 1) return 256;
+    return carve(nullptr, B, N).bytes;
+}
+
+extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det,
+                      int32_t* count, int32_t* keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pred || !det || !count || !workspace) return fail(LP_ERR_ARG, "lp_nms: null pointer");
+    if (B < 1 || N < 1 || max_det < 1) return fail(LP_ERR_ARG, "lp_nms: B, N and max_det must be positive");
+    if (!(conf_thres >= 0.0 && conf_thres <= 1.0) || !(iou_thres >= 0.0 && iou_thres <= 1.0))
+        return fail(LP_ERR_ARG, "lp_nms: thresholds must be in [0, 1]");
+    if (((uintptr_t)workspace & 255) != 0) return fail(LP_ERR_ARG, "lp_nms: workspace must be 256-byte aligned");
+    NmsWs w = carve(workspace, B, N);
+    if (workspace_bytes < w.bytes) return fail(LP_ERR_ARG, "lp_nms: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const float conf_f = (float)conf_thres;
+    float thr_f = (float)iou_thres;                       // largest fp32 not above the double threshold
+    if ((double)thr_f > iou_thres) thr_f = nextafterf(thr_f, -INFINITY);
+
+    LP_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st));
+    const long long nrows = (long long)B * N;
+    long long blocks = (nrows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, B, N, conf_f, w.rows, w.keys, w.cnt, w.NP);
+    hipLaunchKernelGGL(sort_kernel, dim3((unsigned)B), dim3(1024), 0, st, w.keys, w.cnt, w.NP);
+    hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)B), dim3(NMS_T), 0, st, w.keys, w.rows, w.sbox, w.kept, w.cnt, N, w.NP,
+                       thr_f, max_det, det, count, keep);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
+}

@@ -1,0 +1,81 @@
+"""ctypes binding of libyololp_hip.so (C ABI declared in include/lp_hip.h).
+
+The library is the only implementation of the GPU path: if it cannot be loaded
+this module raises -- nothing falls back to eager torch ops on a GPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+LP_F16, LP_BF16, LP_F32 = 0, 1, 2
+LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
+LP_PRED_COLS, LP_DET_COLS, LP_MAX_SRC = 290, 28, 4
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # .../yolo-lp_amd
+LIB_PATH = os.path.join(_PKG_ROOT, 'libyololp_hip.so')
+CSRC_DIR = os.path.join(_PKG_ROOT, 'csrc')
+
+
+class ConvDesc(ctypes.Structure):
+    """lp_conv_desc"""
+    _fields_ = [('n_src', c_int), ('src', c_int * LP_MAX_SRC), ('dst', c_int), ('ksize', c_int), ('stride', c_int),
+                ('act', c_int), ('res', c_int), ('res_alpha', c_float), ('weight', c_void_p), ('bias', c_void_p)]
+
+
+#: name -> (restype, argtypes): every symbol include/lp_hip.h declares
+SYMBOLS = {
+    'lp_version': (c_char_p, []),
+    'lp_last_error': (c_char_p, []),
+    'lp_engine_create': (c_int, [POINTER(c_void_p), c_int]),
+    'lp_engine_destroy': (None, [c_void_p]),
+    'lp_engine_tensor': (c_int, [c_void_p, c_int, c_int]),
+    'lp_engine_add_input': (c_int, [c_void_p, c_int]),
+    'lp_engine_add_conv': (c_int, [c_void_p, POINTER(ConvDesc)]),
+    'lp_engine_add_deconv2x2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'lp_engine_add_pool5_chain': (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    'lp_engine_add_head_cls': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'lp_engine_add_head_box': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'lp_engine_finalize': (c_int, [c_void_p, c_int]),
+    'lp_engine_weight_bytes': (c_size_t, [c_void_p]),
+    'lp_engine_upload': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'lp_engine_arena_bytes': (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    'lp_engine_bind': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int]),
+    'lp_engine_tensor_info': (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_int), POINTER(c_int),
+                                      POINTER(c_int), POINTER(c_int)]),
+    'lp_engine_num_anchors': (c_int, [c_void_p]),
+    'lp_engine_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'lp_engine_num_ops': (c_int, [c_void_p]),
+    'lp_engine_op_info': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                  POINTER(c_double), POINTER(c_double)]),
+    'lp_engine_profile': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int]),
+    'lp_nms_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once and attach prototypes; raises RuntimeError when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('HIP extension %s is missing: build it with `make -C %s` (or '
+                               '`python -c "import __graft_entry__ as g; g.build()"`). The GPU path has no '
+                               'eager fallback.' % (LIB_PATH, CSRC_DIR))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError here = header and library are out of sync
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=''):
+    """Raise RuntimeError with the library's message for a negative lp_status."""
+    if rc < 0:
+        msg = load().lp_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what or 'libyololp_hip', rc, msg.decode() if msg else '?'))
+    return rc

@@ -1,0 +1,400 @@
+"""Host side of the HIP engine: turns a ``yolov6.models.yolo.Model`` into the op
+graph of libyololp_hip.so (folded weights, NHWC tensors, concat-free sources) and
+runs forward / NMS through the C ABI on torch-owned device memory and torch's
+current stream.
+
+Replaces, on a GPU, ``Model.forward`` (reference yolov6/models/yolo.py:32-40)
+and ``non_max_suppression`` (yolov6/utils/nms.py:31-130).  Weight preparation
+follows the reference's order ``float -> fuse_model -> switch_to_deploy``
+(inferer.py:25-68): modules that are still un-fused are folded on the fly with
+the same formulas, without touching the caller's model.
+"""
+import copy
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from yolov6.hip import abi
+from yolov6.layers import common as L
+
+_DT = {torch.float16: abi.LP_F16, torch.bfloat16: abi.LP_BF16, torch.float32: abi.LP_F32}
+_TORCH_DT = {v: k for k, v in _DT.items()}
+CLS_HEADS = ('pro', 'alp', 'ad0', 'ad1', 'ad2', 'ad3', 'ad4', 'ad5')
+
+
+def _act_of(module):
+    if isinstance(module, nn.ReLU):
+        return abi.LP_ACT_RELU
+    if isinstance(module, (nn.SiLU, L.SiLU)):
+        return abi.LP_ACT_SILU
+    if isinstance(module, nn.Identity):
+        return abi.LP_ACT_NONE
+    raise NotImplementedError('activation %s has no HIP epilogue' % type(module).__name__)
+
+
+def _f32(t):
+    return np.ascontiguousarray(t.detach().float().cpu().numpy())
+
+
+def _fold_conv_bn(conv, bn):
+    """fp32 (weight OIHW, bias) of conv followed by an eval-mode BN, the fuse_conv_and_bn formula
+    (torch_utils.py:50-82) evaluated on fp32 copies: the caller's modules are not modified."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        g, beta = bn.weight.detach().float(), bn.bias.detach().float()
+        mu, var = bn.running_mean.float(), bn.running_var.float()
+        scale = torch.diag(g.div(torch.sqrt(bn.eps + var)))
+        w = torch.mm(scale, w.reshape(w.shape[0], -1)).view(w.shape)
+        b = torch.mm(scale, b.reshape(-1, 1)).reshape(-1) + (beta - g.mul(mu).div(torch.sqrt(var + bn.eps)))
+    return w, b
+
+
+def _folded(m):
+    """Conv / SimConv / Conv_C3, fused or not."""
+    return _fold_conv_bn(m.conv, getattr(m, 'bn', None))
+
+
+class Engine:
+    """One frozen graph + its device buffers for one (model, activation dtype, device)."""
+
+    def __init__(self, dtype, device):
+        self.lib = abi.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.lp_dtype = _DT[dtype]
+        h = ctypes.c_void_p()
+        abi.check(self.lib.lp_engine_create(ctypes.byref(h), self.lp_dtype), 'lp_engine_create')
+        self.h = h
+        self._keep = []            # numpy arrays must outlive the add_* calls
+        self.bound = None          # (B, H, W)
+        self.arena = None
+        self.weights = None
+        self.neck_ids = []
+        self.input_id = self.tensor(3, 0)
+        abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
+
+    @classmethod
+    def from_model(cls, model, dtype, device):
+        eng = cls(dtype, device)
+        with torch.no_grad():
+            eng._build(model)
+        return eng.finish(model.detect.nl)
+
+    def finish(self, n_levels=3):
+        """Freeze the graph, pack the weights and (on a GPU) upload them."""
+        abi.check(self.lib.lp_engine_finalize(self.h, n_levels), 'lp_engine_finalize')
+        self._keep = []
+        self.weight_bytes = self.lib.lp_engine_weight_bytes(self.h)
+        if self.device.type == 'cuda':
+            with torch.cuda.device(self.device):
+                self.weights = torch.empty(self.weight_bytes + 256, dtype=torch.uint8, device=self.device)
+                abi.check(self.lib.lp_engine_upload(self.h, self._aligned(self.weights), self._stream()),
+                          'lp_engine_upload')
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.lp_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------
+    @staticmethod
+    def _aligned(buf):
+        return ctypes.c_void_p((buf.data_ptr() + 255) // 256 * 256)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, arr):
+        self._keep.append(arr)
+        return arr.ctypes.data_as(ctypes.c_void_p)
+
+    def tensor(self, channels, sl):
+        return abi.check(self.lib.lp_engine_tensor(self.h, int(channels), int(sl)), 'lp_engine_tensor')
+
+    def conv(self, srcs, weight, bias, k, s, act, sl, res=None, alpha=0.0):
+        """act(conv(cat(srcs))+b) [+ alpha*res] -> new tensor id; ``sl`` is the sources' log2 stride."""
+        w, b = _f32(weight), _f32(bias)
+        dst = self.tensor(w.shape[0], sl + (1 if s == 2 else 0))
+        d = abi.ConvDesc()
+        d.n_src = len(srcs)
+        for i in range(abi.LP_MAX_SRC):
+            d.src[i] = srcs[i] if i < len(srcs) else -1
+        d.dst, d.ksize, d.stride, d.act = dst, k, s, act
+        d.res = -1 if res is None else res
+        d.res_alpha = float(alpha)
+        d.weight, d.bias = self._ptr(w), self._ptr(b)
+        abi.check(self.lib.lp_engine_add_conv(self.h, ctypes.byref(d)), 'lp_engine_add_conv')
+        return dst
+
+    # -- module -> ops ---------------------------------------------------------
+    def cba(self, m, srcs, sl):
+        """Conv / SimConv / Conv_C3 (common.py:21-66, 466-476)."""
+        w, b = _folded(m)
+        k, s = m.conv.kernel_size[0], m.conv.stride[0]
+        return self.conv(srcs, w, b, k, s, _act_of(m.act), sl)
+
+    def basic(self, m, srcs, sl, res=None, alpha=0.0):
+        """A 'basic block' of the rep-style stages -> one conv op."""
+        if isinstance(m, L.RepVGGBlock):
+            if hasattr(m, 'rbr_reparam'):
+                w, b, s = m.rbr_reparam.weight, m.rbr_reparam.bias, m.rbr_reparam.stride[0]
+            else:
+                mf = m if next(m.parameters()).dtype == torch.float32 else copy.deepcopy(m).float()
+                w, b = mf.get_equivalent_kernel_bias()
+                s = m.rbr_dense.conv.stride[0]
+            return self.conv(srcs, w, b, 3, s, abi.LP_ACT_RELU, sl, res, alpha)
+        if isinstance(m, (L.ConvWrapper, L.SimConvWrapper)):
+            w, b = _folded(m.block)
+            c = m.block.conv
+            return self.conv(srcs, w, b, c.kernel_size[0], c.stride[0], _act_of(m.block.act), sl, res, alpha)
+        if isinstance(m, L.RealVGGBlock):
+            w, b = _fold_conv_bn(m.conv, m.bn)
+            return self.conv(srcs, w, b, 3, m.conv.stride[0], abi.LP_ACT_RELU, sl, res, alpha)
+        raise NotImplementedError('%s has no HIP lowering' % type(m).__name__)
+
+    def stage_block(self, m, srcs, sl):
+        """One element of a RepBlock: a basic block or a BottleRep (common.py:437-455)."""
+        if isinstance(m, L.BottleRep):
+            assert len(srcs) == 1 or not m.shortcut
+            y = self.basic(m.conv1, srcs, sl)
+            if m.shortcut:
+                alpha = float(m.alpha) if not torch.is_tensor(m.alpha) else float(m.alpha.detach().float().item())
+                return self.basic(m.conv2, [y], sl, res=srcs[0], alpha=alpha)
+            return self.basic(m.conv2, [y], sl)
+        return self.basic(m, srcs, sl)
+
+    def rep_block(self, m, srcs, sl):
+        """RepBlock (common.py:416-434)."""
+        x = self.stage_block(m.conv1, srcs, sl)
+        if m.block is not None:
+            for blk in m.block:
+                x = self.stage_block(blk, [x], sl)
+        return x
+
+    def bepc3(self, m, srcs, sl):
+        """BepC3 (common.py:479-501): cv3 reads [m(cv1 x), cv2 x] as two sources."""
+        a = self.rep_block(m.m, [self.cba(m.cv1, srcs, sl)], sl)
+        if m.concat is True:
+            return self.cba(m.cv3, [a, self.cba(m.cv2, srcs, sl)], sl)
+        return self.cba(m.cv3, [a], sl)
+
+    def stage(self, m, srcs, sl):
+        if isinstance(m, L.RepBlock):
+            return self.rep_block(m, srcs, sl)
+        if isinstance(m, L.BepC3):
+            return self.bepc3(m, srcs, sl)
+        raise NotImplementedError('%s has no HIP lowering' % type(m).__name__)
+
+    def pools(self, x, sl, c):
+        ids = [self.tensor(c, sl) for _ in range(3)]
+        abi.check(self.lib.lp_engine_add_pool5_chain(self.h, x, *ids), 'lp_engine_add_pool5_chain')
+        return ids
+
+    def merge_layer(self, m, x, sl):
+        """SimCSPSPPF / CSPSPPF (common.py:124-172) or SimSPPF / SPPF (:88-121); concats are multi-source reads."""
+        if isinstance(m, L._CSPSPPFBase):
+            x1 = self.cba(m.cv4, [self.cba(m.cv3, [self.cba(m.cv1, [x], sl)], sl)], sl)
+            y0 = self.cba(m.cv2, [x], sl)
+            y3 = self.cba(m.cv6, [self.cba(m.cv5, [x1] + self.pools(x1, sl, m.cv4.conv.out_channels), sl)], sl)
+            return self.cba(m.cv7, [y0, y3], sl)
+        if isinstance(m, L._SPPFBase):
+            x1 = self.cba(m.cv1, [x], sl)
+            return self.cba(m.cv2, [x1] + self.pools(x1, sl, m.cv1.conv.out_channels), sl)
+        raise NotImplementedError('%s has no HIP lowering' % type(m).__name__)
+
+    def bifusion(self, m, x0, sl0, x1, x2):
+        """BiFusion (common.py:504-527): x0 at stride sl0 is upsampled 2x; x1 is at sl0-1; x2 at sl0-2."""
+        t = m.upsample.upsample_transpose
+        up = self.tensor(t.out_channels, sl0 - 1)
+        abi.check(self.lib.lp_engine_add_deconv2x2(self.h, x0, up, self._ptr(_f32(t.weight)), self._ptr(_f32(t.bias))),
+                  'lp_engine_add_deconv2x2')
+        a = self.cba(m.cv1, [x1], sl0 - 1)
+        d = self.cba(m.downsample, [self.cba(m.cv2, [x2], sl0 - 2)], sl0 - 2)
+        return self.cba(m.cv3, [up, a, d], sl0 - 1)
+
+    def _build(self, model):
+        bb, nk, det = model.backbone, model.neck, model.detect
+        if not getattr(bb, 'fuse_P2', False):
+            raise NotImplementedError('the BiFPAN necks need the P2 output (fuse_P2=True)')
+        x = self.basic(bb.stem, [self.input_id], 0)
+        feats = []
+        for i, sl in zip((2, 3, 4, 5), (1, 2, 3, 4)):          # sl = stride log2 of the stage input
+            st = getattr(bb, 'ERBlock_%d' % i)
+            x = self.basic(st[0], [x], sl)
+            x = self.stage(st[1], [x], sl + 1)
+            if len(st) > 2:
+                x = self.merge_layer(st[2], x, sl + 1)
+            feats.append(x)
+        x3, x2, x1, x0 = feats                                    # strides 4, 8, 16, 32  (reppan.py:216)
+        fpn0 = self.cba(nk.reduce_layer0, [x0], 5)
+        f0 = self.stage(nk.Rep_p4, [self.bifusion(nk.Bifusion0, fpn0, 5, x1, x2)], 4)
+        fpn1 = self.cba(nk.reduce_layer1, [f0], 4)
+        pan2 = self.stage(nk.Rep_p3, [self.bifusion(nk.Bifusion1, fpn1, 4, x2, x3)], 3)
+        pan1 = self.stage(nk.Rep_n3, [self.cba(nk.downsample2, [pan2], 3), fpn1], 4)
+        pan0 = self.stage(nk.Rep_n4, [self.cba(nk.downsample1, [pan1], 4), fpn0], 5)
+        self.neck_ids = [pan2, pan1, pan0]
+        if det.nl != 3:
+            raise NotImplementedError('P6 heads are outside the hot-path scope')
+        for i, f in enumerate(self.neck_ids):                     # effidehead.py:228-245
+            sl = 3 + i
+            s = self.cba(det.stems[i], [f], sl)
+            c = self.cba(det.cls_convs[i], [s], sl)
+            preds = [getattr(det, '%s_preds' % h)[i] for h in CLS_HEADS]
+            wc = np.concatenate([_f32(p.weight).reshape(p.out_channels, -1) for p in preds], 0)
+            bc = np.concatenate([_f32(p.bias) for p in preds], 0)
+            abi.check(self.lib.lp_engine_add_head_cls(self.h, c, i, wc.shape[0], self._ptr(wc), self._ptr(bc)),
+                      'lp_engine_add_head_cls')
+            r = self.cba(det.reg_convs[i], [s], sl)
+            rp, cp = det.reg_preds[i], det.cor_preds[i]
+            bins = det.reg_max + 1 if det.use_dfl else 1
+            if rp.out_channels != 4 * bins:
+                raise NotImplementedError('reg_preds width %d does not match use_dfl/reg_max' % rp.out_channels)
+            wb = np.concatenate([_f32(rp.weight).reshape(rp.out_channels, -1), _f32(cp.weight).reshape(8, -1)], 0)
+            bbias = np.concatenate([_f32(rp.bias), _f32(cp.bias)], 0)
+            proj = self._ptr(_f32(det.proj_conv.weight).reshape(-1)) if bins > 1 else None
+            abi.check(self.lib.lp_engine_add_head_box(self.h, r, i, bins, self._ptr(wb), self._ptr(bbias), proj),
+                      'lp_engine_add_head_box')
+
+    # -- execution ---------------------------------------------------------------
+    def bind(self, B, H, W):
+        if self.bound == (B, H, W):
+            return
+        if H % 32 or W % 32:
+            raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
+        need = self.lib.lp_engine_arena_bytes(self.h, B, H, W)
+        if need == 0:
+            raise ValueError('bad input shape %s' % ((B, H, W),))
+        if self.arena is None or self.arena.numel() < need + 256:
+            self.arena = None
+            self.arena = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)
+        abi.check(self.lib.lp_engine_bind(self.h, self._aligned(self.arena), need, B, H, W), 'lp_engine_bind')
+        self.bound = (B, H, W)
+        self.n_anchors = self.lib.lp_engine_num_anchors(self.h)
+
+    def tensor_view(self, tid):
+        """Zero-copy [B,C,h,w] view (channels_last strides) of an arena tensor."""
+        off, c, cs, h, w = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        abi.check(self.lib.lp_engine_tensor_info(self.h, tid, ctypes.byref(off), ctypes.byref(c), ctypes.byref(cs),
+                                                 ctypes.byref(h), ctypes.byref(w)), 'lp_engine_tensor_info')
+        B = self.bound[0]
+        esz = torch.empty(0, dtype=self.dtype).element_size()
+        base = (self.arena.data_ptr() + 255) // 256 * 256 - self.arena.data_ptr() + off.value
+        n = B * h.value * w.value * cs.value
+        flat = self.arena[base:base + n * esz].view(self.dtype)
+        return flat.view(B, h.value, w.value, cs.value)[..., :c.value].permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
+        if x.dtype not in _DT:
+            raise TypeError('unsupported input dtype %s' % x.dtype)
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        with torch.cuda.device(self.device):
+            self.bind(B, H, W)
+            pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
+            abi.check(self.lib.lp_engine_forward(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
+                                                 ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
+        return pred
+
+    def profile(self, x, reps=3):
+        """Per-op device milliseconds (hipEvent pairs) + op descriptions, for bench.py."""
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        with torch.cuda.device(self.device):
+            self.bind(B, H, W)
+            pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
+            n = self.lib.lp_engine_num_ops(self.h)
+            ms = (ctypes.c_float * n)()
+            abi.check(self.lib.lp_engine_profile(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
+                                                 ctypes.c_void_p(pred.data_ptr()), self._stream(), ms, reps),
+                      'lp_engine_profile')
+        ops = []
+        for i in range(n):
+            kind, ks, cin, cout = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            abi.check(self.lib.lp_engine_op_info(self.h, i, ctypes.byref(kind), ctypes.byref(ks), ctypes.byref(cin),
+                                                 ctypes.byref(cout), ctypes.byref(fl), ctypes.byref(by)), 'lp_engine_op_info')
+            ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box')[kind.value], ksize=ks.value,
+                            cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i])))
+        return ops
+
+
+def _weights_version(model):
+    return sum(t._version for t in list(model.parameters()) + list(model.buffers()))
+
+
+def engine_for(model, dtype=None):
+    """Cached engine of a model; rebuilt when the weights were modified in place or the dtype changed."""
+    p = next(model.parameters())
+    if not p.is_cuda:
+        raise RuntimeError('model is not on a GPU')
+    dtype = dtype or getattr(model, 'lp_dtype', None) or p.dtype
+    if dtype not in _DT:
+        raise TypeError('unsupported activation dtype %s' % dtype)
+    key = (dtype, p.device, _weights_version(model))
+    cached = model.__dict__.get('_lp_engine')
+    if cached is None or cached[0] != key:
+        cached = (key, Engine.from_model(model, dtype, p.device))
+        model.__dict__['_lp_engine'] = cached
+    return cached[1]
+
+
+def model_forward(model, x):
+    """``Model.forward`` on a GPU: [pred[B,N,290] fp32, [f_s8, f_s16, f_s32]].  The feature maps are
+    zero-copy channels_last views of the engine's arena (valid until the next forward of this model)."""
+    eng = engine_for(model)
+    pred = eng.forward(x)
+    return [pred, [eng.tensor_view(t) for t in eng.neck_ids]]
+
+
+# ---------------------------------------------------------------------------------------------------
+_nms_ws = {}
+
+
+def nms_padded(prediction, conf_thres, iou_thres, max_det, want_keep=False):
+    """Batch NMS through lp_nms without a host sync: (det[B,max_det,28], count[B] int32, keep or None)."""
+    if not (prediction.is_cuda and prediction.dtype == torch.float32 and prediction.is_contiguous()):
+        raise ValueError('prediction must be a contiguous fp32 CUDA tensor')
+    B, N, C = prediction.shape
+    if C != abi.LP_PRED_COLS:
+        raise ValueError('prediction must have %d columns, got %d' % (abi.LP_PRED_COLS, C))
+    lib = abi.load()
+    dev = prediction.device
+    with torch.cuda.device(dev):
+        need = lib.lp_nms_workspace_bytes(B, N)
+        ws = _nms_ws.get(dev)
+        if ws is None or ws.numel() < need + 256:
+            ws = _nms_ws[dev] = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        det = torch.empty(B, max_det, abi.LP_DET_COLS, dtype=torch.float32, device=dev)
+        count = torch.empty(B, dtype=torch.int32, device=dev)
+        keep = torch.empty(B, max_det, dtype=torch.int32, device=dev) if want_keep else None
+        abi.check(lib.lp_nms(ctypes.c_void_p(prediction.data_ptr()), B, N, float(conf_thres), float(iou_thres),
+                             int(max_det), ctypes.c_void_p(det.data_ptr()), ctypes.c_void_p(count.data_ptr()),
+                             ctypes.c_void_p(keep.data_ptr()) if want_keep else None,
+                             ctypes.c_void_p((ws.data_ptr() + 255) // 256 * 256), need,
+                             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'lp_nms')
+    return det, count, keep
+
+
+def non_max_suppression(prediction, conf_thres, iou_thres, max_det):
+    """Reference-shaped result: list (len B) of [n_i, 28] tensors; one host sync for the whole batch."""
+    B, N = prediction.shape[0], prediction.shape[1]
+    if B == 0 or N == 0:
+        return [torch.zeros((0, 28), device=prediction.device)] * B
+    src = prediction
+    work = prediction
+    if work.dtype != torch.float32 or not work.is_contiguous():
+        work = work.float().contiguous()
+    det, count, _ = nms_padded(work, conf_thres, iou_thres, max_det)
+    if work is not src:
+        src.copy_(work)          # keep the reference's in-place obj*cls side effect on the caller's tensor
+    counts = count.cpu().tolist()
+    return [det[b, :n] for b, n in enumerate(counts)]
