@@ -58,7 +58,7 @@ CONV_CASES = [
 def test_conv(case, dtype):
     from yolov6.hip import abi
     cins, cout, k, s, act, use_res, h, w, B = case
-    sl = 2
+    sl = 5          # source tensors at 1/32 resolution: any h, w gives an input size the engine accepts
     eng = _engine(dtype)
     srcs = [eng.tensor(c, sl) for c in cins]
     cin = sum(cins)
@@ -95,16 +95,16 @@ def test_deconv2x2(cin, cout, h, w, dtype):
     from yolov6.hip import abi
     from yolov6.hip.runtime import _f32
     eng = _engine(dtype)
-    src, dst = eng.tensor(cin, 3), eng.tensor(cout, 2)
+    src, dst = eng.tensor(cin, 5), eng.tensor(cout, 4)
     wt = _rand((cin, cout, 2, 2), 3, (1.0 / cin) ** 0.5)
     bias = _rand((cout,), 4, 0.5)
     abi.check(eng.lib.lp_engine_add_deconv2x2(eng.h, src, dst, eng._ptr(_f32(wt)), eng._ptr(_f32(bias))))
     eng.finish()
     B = 2
-    eng.bind(B, h * 8, w * 8)
+    eng.bind(B, h * 32, w * 32)
     x = _rand((B, cin, h, w), 5)
     _fill(eng, src, x)
-    _run(eng, B, h * 8, w * 8)
+    _run(eng, B, h * 32, w * 32)
     got = eng.tensor_view(dst).float().cpu()
     q = lambda t: t.to(dtype).float()
     ref = F.conv_transpose2d(q(x), q(wt), bias, stride=2)

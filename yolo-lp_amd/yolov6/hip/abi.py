@@ -60,6 +60,9 @@ def load():
     """Load the library once and attach prototypes; raises RuntimeError when it is missing."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64; importing it first makes this library bind to that same HIP
+        # runtime (one runtime per process: a second copy loaded from /opt/rocm finds no device)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('HIP extension %s is missing: build it with `make -C %s` (or '
                                '`python -c "import __graft_entry__ as g; g.build()"`). The GPU path has no '
