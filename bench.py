@@ -38,7 +38,21 @@ def parse():
     ap.add_argument('--max-det', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
     return ap.parse_args()
+
+
+def host_cores():
+    """Threads this process may really use: affinity mask and cgroup quota, capped at the GPU box's 16-core share
+    per GPU (os.cpu_count() reports all 256 host threads there and oversubscribing them is ~100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
 
 
 def cpu_baseline(model_name, sigma, size, conf, iou, max_det, budget_s):
@@ -51,7 +65,7 @@ def cpu_baseline(model_name, sigma, size, conf, iou, max_det, budget_s):
     a = lp_oracle.arch(model_name)
     B = 2
     x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(1234))
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
 
     def step():
@@ -151,6 +165,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             t_nms.append(e0.elapsed_time(e1))
+        if args.detail:
+            with open(args.detail, 'w') as f:
+                for i, o in enumerate(ops):
+                    f.write('%3d %-8s k%d %4d->%4d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s (algorithmic)\n'
+                            % (i, o['kind'], o['ksize'], o['cin'], o['cout'], o['ms'] * 1e3,
+                               o['flops'] / max(o['ms'], 1e-9) / 1e9, o['bytes'] / max(o['ms'], 1e-9) / 1e6))
         conv3 = [o for o in ops if o['kind'] == 'conv' and o['ksize'] == 3]
         allmm = [o for o in ops if o['kind'] in ('conv', 'deconv', 'head_cls', 'head_box')]
         fl3, ms3 = sum(o['flops'] for o in conv3), sum(o['ms'] for o in conv3)

@@ -4,14 +4,14 @@
 
 namespace lp {
 
-int conv_launch_f16(int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st);
-int conv_launch_bf16(int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st);
-int conv_launch_f32(int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st);
+int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
+int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
+int conv_launch_f32(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
     const int sz = (int)dtype_size(dtype);
     ConvShape s;
-    const int wc = cfg == CFG_C ? 1 : 2, wp = 2, wgc = cfg == CFG_A ? 2 : 1, wgp = cfg == CFG_A ? 2 : 4;
+    const int wc = cfg == CFG_C ? 1 : 2, wp = 2, wgc = (cfg == CFG_A || cfg == CFG_D) ? 2 : 1, wgp = cfg == CFG_A ? 2 : 4;
     s.CB = 32 * wc * wgc;
     s.PB = 32 * wp * wgp;
     s.NT = 64 * wgc * wgp;
@@ -37,7 +37,7 @@ void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, i
     *TW = bw;
 }
 
-int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st) {
+int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
     // host-side shape checks: the kernel indexes LDS and global memory from these without further tests
     const ConvShape s = conv_shape(dtype, cfg, ksize, stride);
     const int hh = (a.TH - 1) * stride + ksize, hw = (a.TW - 1) * stride + ksize;
@@ -47,9 +47,9 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, const ConvA
     if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nphase < 1) return fail(LP_ERR_ARG, "conv: bad counts");
     if (mode == MODE_DECODE && (a.nct != 1 || 4 * a.reg_bins + 8 > s.CB)) return fail(LP_ERR_ARG, "decode: cout tile");
     switch (dtype) {
-        case LP_F16: return conv_launch_f16(cfg, mode, ksize, stride, a, st);
-        case LP_BF16: return conv_launch_bf16(cfg, mode, ksize, stride, a, st);
-        case LP_F32: return conv_launch_f32(cfg, mode, ksize, stride, a, st);
+        case LP_F16: return conv_launch_f16(cfg, mode, ksize, stride, nbuf, a, st);
+        case LP_BF16: return conv_launch_bf16(cfg, mode, ksize, stride, nbuf, a, st);
+        case LP_F32: return conv_launch_f32(cfg, mode, ksize, stride, nbuf, a, st);
     }
     return fail(LP_ERR_ARG, "conv: dtype");
 }

@@ -4,6 +4,7 @@
 #include "lp_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct Op {
     int level = 0, reg_bins = 1;
     std::vector<float> weight, bias, proj;  // host fp32, reference layouts
     // filled by finalize
-    int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1;
+    int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1;
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -257,6 +258,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
     const size_t esz = dtype_size(dt);
     std::vector<unsigned char>& blob = e->blob;
     blob.clear();
+    blob.resize(256, 0);   // zero page: DMA source for padding granules (ConvArgs::zero)
     auto align = [&]() { blob.resize((blob.size() + 255) / 256 * 256, 0); };
     for (Op& op : e->ops) {
         if (op.kind == OP_INPUT || op.kind == OP_POOL) continue;
@@ -265,7 +267,16 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         int cout_store;
         if (op.kind == OP_HEAD_CLS) { op.mode = MODE_PRED; op.cfg = CFG_B; cout_store = op.cout; }
         else if (op.kind == OP_HEAD_BOX) { op.mode = MODE_DECODE; op.cfg = CFG_A; cout_store = op.cout; }
-        else { op.mode = MODE_ACT; cout_store = e->tensors[op.dst].cs; op.cfg = pick_cfg(dt, ks, st, cout_store); }
+        else {
+            op.mode = MODE_ACT;
+            cout_store = e->tensors[op.dst].cs;
+            op.cfg = pick_cfg(dt, ks, st, cout_store);
+            // experiment knobs (read once, at finalize): LP_TUNE_CFG128 replaces CFG_A, LP_TUNE_NBUF sets the ring depth
+            const char* tc = getenv("LP_TUNE_CFG128");
+            const char* tb = getenv("LP_TUNE_NBUF");
+            if (tc && op.cfg == CFG_A) op.cfg = atoi(tc);
+            if (tb && op.cfg != CFG_C) op.nbuf = atoi(tb) == 2 ? 2 : 1;
+        }
         const ConvShape s = conv_shape(dt, op.cfg, ks, st);
         op.nct = ceil_div(cout_store, s.CB);
         op.nphase = op.kind == OP_DECONV ? 4 : 1;
@@ -297,6 +308,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
                                 const int co = ct * s.CB + cl;
                                 if (co >= op.cout) continue;
                                 const size_t row = ((((size_t)ph * op.nct + ct) * op.nchunks + q) * taps + tp) * s.CB + cl;
+                                const int srow = tp * s.CB + cl;   // row inside the staged slab: decides the granule swizzle
                                 for (int kc = 0; kc < s.KC; ++kc) {
                                     const int c = c0 + kc;
                                     if (c >= t.c) break;
@@ -306,7 +318,9 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
                                         v = op.weight[((size_t)ci * op.cout + co) * 4 + ph];
                                     else                        // Conv2d weight [Cout][Cin][k][k]
                                         v = op.weight[((size_t)co * op.cin + ci) * taps + tp];
-                                    put_elem(wp, row * s.KC + kc, v, dt);
+                                    const int epg = 16 / (int)esz, gpr = s.KC / epg;
+                                    const int pos = gpr == 2 ? ((kc / epg) ^ ((srow >> 3) & 1)) : ((kc / epg) ^ ((srow >> 1) & 7));
+                                    put_elem(wp, row * s.KC + (size_t)pos * epg + kc % epg, v, dt);
                                 }
                             }
                     }
@@ -443,6 +457,7 @@ static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float*
     a.nsrc = op.nsrc;
     for (int i = 0; i < op.nsrc; ++i) { a.src[i].ptr = tptr(op.src[i]); a.src[i].cs = e->tensors[op.src[i]].cs; }
     for (int i = 0; i <= LP_MAX_SRC; ++i) a.chunk_begin[i] = op.chunk_begin[i];
+    a.zero = e->dev_w;
     a.w = e->dev_w + op.w_off;
     a.bias = (const float*)(e->dev_w + op.b_off);
     const Tensor& s0 = e->tensors[op.src[0]];
@@ -483,7 +498,7 @@ static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float*
             a.stride_px = (float)(8 << op.level);
         }
     }
-    return conv_launch(dt, op.cfg, op.mode, ks, stv, a, st);
+    return conv_launch(dt, op.cfg, op.mode, ks, stv, op.nbuf, a, st);
 }
 
 static int check_ready(const lp_engine* e, const void* x, int x_dtype) {

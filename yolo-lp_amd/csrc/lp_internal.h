@@ -28,7 +28,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- conv launch description ----------------------------------------------------------------------
 enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
-enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/ };
+enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/ };
 
 struct ConvSrc {
     const void* ptr;
@@ -41,6 +41,7 @@ struct ConvArgs {
     int nsrc;
     const void* w;          // packed [phase][cout_tile][chunk][tap][CB][KC]
     const float* bias;      // [phase?][nct*CB]  (same for every phase)
+    const void* zero;       // >= 16 zero bytes: DMA source of out-of-image / out-of-range granules
     void* out;
     const void* res;        // residual (same dtype/geometry as out) or null
     int res_cs;
@@ -68,7 +69,7 @@ struct ConvShape {  // compile-time geometry of one kernel configuration, mirror
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride);
 // Picks the output tile (TH x TW <= PB output pixels, halo <= HPMAX) that needs the fewest blocks.
 void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW);
-int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, const ConvArgs& a, hipStream_t st);
+int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
