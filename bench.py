@@ -138,9 +138,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(args.steps):
             out = step()
+        ev1.record()
+        t_issue = time.perf_counter() - t0          # host time to enqueue all steps
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -168,8 +172,8 @@ def main():
         if args.detail:
             with open(args.detail, 'w') as f:
                 for i, o in enumerate(ops):
-                    f.write('%3d %-8s k%d %4d->%4d  %8.1f us  %7.1f TFLOP/s  %7.1f GB/s (algorithmic)\n'
-                            % (i, o['kind'], o['ksize'], o['cin'], o['cout'], o['ms'] * 1e3,
+                    f.write('%3d %-8s k%d %4d->%4d %s %8.1f us  %7.1f TFLOP/s  %7.1f GB/s (algorithmic)\n'
+                            % (i, o['kind'], o['ksize'], o['cin'], o['cout'], o['variant'], o['ms'] * 1e3,
                                o['flops'] / max(o['ms'], 1e-9) / 1e9, o['bytes'] / max(o['ms'], 1e-9) / 1e6))
         conv3 = [o for o in ops if o['kind'] == 'conv' and o['ksize'] == 3]
         allmm = [o for o in ops if o['kind'] in ('conv', 'deconv', 'head_cls', 'head_box')]
@@ -196,7 +200,9 @@ def main():
                                    '(sigma %.2f), conf %.2f iou %.2f max_det %d'
                                    % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
                        'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
-                       'mean_detections_per_image': round(counts, 1)},
+                       'mean_detections_per_image': round(counts, 1),
+                       'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
+                       'device_ms_per_step': round(ev0.elapsed_time(ev1) / args.steps, 3)},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -124,6 +124,14 @@ int lp_engine_op_info(const lp_engine* e, int op, int* kind, int* ksize, int* ci
                       double* bytes);
 int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps);
 
+/* Pick, per conv op and for the bound shape, the fastest of the kernel variants (workgroup tile / LDS ring depth)
+ * that share the op's weight packing, by timing each in place (hipEvent pairs on `stream`).  The choice is
+ * remembered per (B,H,W) and re-applied by lp_engine_bind.  Variants differ only in tiling: every output element
+ * is the same fp32 sum in the same K order, so results do not depend on the choice.  lp_engine_op_variant reports
+ * the current choice of an op (cfg: 0..4 = workgroup tile A..E, nbuf: LDS ring depth 1 or 2). */
+int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
+int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
+
 /* ---------------------------------------------------------------------------------------------------
  * Post-processing.  Replaces non_max_suppression (yolov6/utils/nms.py:31-130) including its call of
  * torchvision.ops.nms (:121).  All images of the batch are processed by one set of launches.

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of one conv layer of the HIP engine (for rocprofv3 --pmc runs and variant A/B tests).
+
+    LP_AUTOTUNE=0 LP_TUNE_CFG128=3 LP_TUNE_NBUF=1 python tools/conv_bench.py --cin 256 --cout 256 --hw 40 --batch 32
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from yolov6.hip import abi  # noqa: E402
+from yolov6.hip.runtime import Engine  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--cin', type=int, default=256)
+ap.add_argument('--cout', type=int, default=256)
+ap.add_argument('--k', type=int, default=3)
+ap.add_argument('--s', type=int, default=1)
+ap.add_argument('--hw', type=int, default=40, help='feature-map height = width at the conv input')
+ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--iters', type=int, default=50)
+ap.add_argument('--dtype', default='f16')
+args = ap.parse_args()
+
+dt = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}[args.dtype]
+eng = Engine(dt, 'cuda:0')
+eng.autotune = False
+sl = 5
+src = eng.tensor(args.cin, sl)
+g = torch.Generator().manual_seed(0)
+w = torch.randn(args.cout, args.cin, args.k, args.k, generator=g) * (2.0 / (args.cin * args.k * args.k)) ** 0.5
+dst = eng.conv([src], w, torch.zeros(args.cout), args.k, args.s, abi.LP_ACT_RELU, sl)
+eng.finish()
+H = W = args.hw << sl
+eng.bind(args.batch, H, W)
+eng.tensor_view(src).copy_(torch.randn(args.batch, args.cin, args.hw, args.hw, generator=g).to('cuda:0', dt))
+ops = eng.profile(torch.zeros(args.batch, 3, H, W, device='cuda:0', dtype=dt), reps=args.iters)
+o = ops[1]
+print('%s k%d s%d %d->%d @%dx%d B%d variant %s: %.1f us  %.1f TFLOP/s' % (
+    args.dtype, args.k, args.s, args.cin, args.cout, args.hw, args.hw, args.batch, o['variant'], o['ms'] * 1e3,
+    o['flops'] / o['ms'] / 1e9))

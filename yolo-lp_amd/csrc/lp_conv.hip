@@ -11,13 +11,64 @@ int conv_launch_f32(int cfg, int mode, int ksize, int stride, int nbuf, const Co
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
     const int sz = (int)dtype_size(dtype);
     ConvShape s;
-    const int wc = cfg == CFG_C ? 1 : 2, wp = 2, wgc = (cfg == CFG_A || cfg == CFG_D) ? 2 : 1, wgp = cfg == CFG_A ? 2 : 4;
+    int wc = 2, wp = 2, wgc = 1, wgp = 4;
+    switch (cfg) {
+        case CFG_A: wgc = 2; wgp = 2; break;
+        case CFG_B: break;
+        case CFG_C: wc = 1; break;
+        case CFG_D: wgc = 2; wgp = 4; break;
+        case CFG_E: wc = 4; break;
+    }
+    s.WP = wp;
+    s.WGC = wgc;
+    s.WGP = wgp;
     s.CB = 32 * wc * wgc;
     s.PB = 32 * wp * wgp;
     s.NT = 64 * wgc * wgp;
     s.KC = ksize == 1 ? 128 / sz : 32 / sz;
-    s.HPMAX = ksize == 1 ? s.PB : (stride == 1 ? s.PB + s.PB / 2 + 64 : 4 * s.PB + s.PB / 2 + 64);
+    s.HPMAX = ksize == 1 ? s.PB : (stride == 1 ? 2 * s.PB + 128 : 5 * s.PB + 128);
     return s;
+}
+
+static inline int swz_host(int row, int g, int gpr) { return gpr == 2 ? (g ^ ((row >> 3) & 1)) : (g ^ ((row >> 1) & 7)); }
+
+int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW) {
+    const int hw = (TW - 1) * stride + ksize, hh = (TH - 1) * stride + ksize;
+    if (ksize == 1) return hw;   // 128-B rows of consecutive pixels: the row swizzle alone is conflict-free
+    (void)dtype;
+    const int rowb = 32, gpr = 2, npix = TH * TW;
+    // the four 16-lane groups one ds_read_b128 is serviced in (lanes >= 32 mirror them)
+    static const int G0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+    static const int G1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+    long best_cost = -1;
+    int best = hw;
+    for (int pitch = hw; pitch < hw + 16; ++pitch) {
+        if (hh * pitch > s.HPMAX) break;
+        long cost = 0;
+        for (int blk = 0; blk * 32 < s.PB; ++blk)
+            for (int t = 0; t < ksize * ksize; ++t)
+                for (int half = 0; half < 2; ++half)
+                    for (int g = 0; g < 2; ++g) {
+                        const int* lanes = g ? G1 : G0;
+                        int addr[16], n = 0, slot_cnt[16] = {0};
+                        for (int k = 0; k < 16; ++k) {
+                            int pl = blk * 32 + lanes[k];
+                            if (pl >= npix) pl = 0;
+                            const int ty = pl / TW, tx = pl - ty * TW;
+                            const int hp = (ty * stride + t / ksize) * pitch + tx * stride + t % ksize;
+                            const int a = hp * rowb + swz_host(hp, half, gpr) * 16;
+                            bool dup = false;
+                            for (int m = 0; m < n; ++m) dup |= addr[m] == a;   // identical addresses broadcast
+                            if (!dup) { addr[n++] = a; ++slot_cnt[(a >> 4) & 15]; }
+                        }
+                        int mx = 1;
+                        for (int k = 0; k < 16; ++k) mx = slot_cnt[k] > mx ? slot_cnt[k] : mx;
+                        cost += mx;
+                    }
+        cost = cost * 64 + (pitch - hw);   // fewest LDS cycles first, then the least padding
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pitch; }
+    }
+    return best;
 }
 
 void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW) {
@@ -41,7 +92,7 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, c
     // host-side shape checks: the kernel indexes LDS and global memory from these without further tests
     const ConvShape s = conv_shape(dtype, cfg, ksize, stride);
     const int hh = (a.TH - 1) * stride + ksize, hw = (a.TW - 1) * stride + ksize;
-    if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || hh * hw > s.HPMAX)
+    if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || a.hpitch < hw || hh * a.hpitch > s.HPMAX)
         return fail(LP_ERR_ARG, "conv: tile does not fit the kernel configuration");
     if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv: tiles do not cover the output");
     if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nphase < 1) return fail(LP_ERR_ARG, "conv: bad counts");

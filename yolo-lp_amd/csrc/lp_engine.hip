@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 namespace lp {
@@ -44,6 +46,13 @@ struct Op {
     long long w_phase_stride = 0;              // elements
 };
 
+struct Launch {
+    ConvArgs a;
+    long long pred_off = 0;
+    int cfg = 0, mode = 0, ks = 1, st = 1, nbuf = 1;
+    bool is_conv = false;
+};
+
 }  // namespace lp
 
 using namespace lp;
@@ -61,8 +70,11 @@ struct lp_engine {
     int B = 0, H = 0, W = 0, n_anchors = 0;
     std::vector<int> level_off;       // first pred row of each level
     std::vector<hipEvent_t> events;
+    std::vector<Launch> launches;     // per op, prepared at bind / after tuning
+    std::map<std::vector<int>, std::vector<std::pair<int, int>>> tuned;  // (B,H,W) -> per-op (cfg, nbuf)
 };
 
+static int prepare_op(lp_engine* e, size_t idx);
 static bool valid_tensor(const lp_engine* e, int id) { return id >= 0 && id < (int)e->tensors.size(); }
 
 extern "C" const char* lp_version(void) { return "yololp-hip 0.1 (gfx950)"; }
@@ -271,10 +283,12 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
             op.mode = MODE_ACT;
             cout_store = e->tensors[op.dst].cs;
             op.cfg = pick_cfg(dt, ks, st, cout_store);
-            // experiment knobs (read once, at finalize): LP_TUNE_CFG128 replaces CFG_A, LP_TUNE_NBUF sets the ring depth
+            // default variant of the 128-cout class; lp_engine_autotune() picks per layer among the variants that
+            // share this packing.  LP_TUNE_CFG128 / LP_TUNE_NBUF force one for experiments.
+            if (op.cfg == CFG_A) op.cfg = CFG_E;
             const char* tc = getenv("LP_TUNE_CFG128");
             const char* tb = getenv("LP_TUNE_NBUF");
-            if (tc && op.cfg == CFG_A) op.cfg = atoi(tc);
+            if (tc && op.cfg == CFG_E) op.cfg = atoi(tc);
             if (tb && op.cfg != CFG_C) op.nbuf = atoi(tb) == 2 ? 2 : 1;
         }
         const ConvShape s = conv_shape(dt, op.cfg, ks, st);
@@ -389,6 +403,15 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     e->level_off.assign(e->n_levels + 1, 0);
     for (int l = 0; l < e->n_levels; ++l) e->level_off[l + 1] = e->level_off[l] + (H >> (3 + l)) * (W >> (3 + l));
     e->n_anchors = e->level_off[e->n_levels];
+    if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
+    auto it = e->tuned.find({B, H, W});
+    if (it != e->tuned.end())
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i].first; e->ops[i].nbuf = it->second[i].second; }
+    e->launches.assign(e->ops.size(), Launch());
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        int rc = prepare_op(e, i);
+        if (rc) return rc;
+    }
     return LP_OK;
 }
 
@@ -442,17 +465,17 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
 }
 
 // ---- execution ------------------------------------------------------------------------------------------
-static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float* pred, hipStream_t st) {
+// Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
+static int prepare_op(lp_engine* e, size_t idx) {
+    const Op& op = e->ops[idx];
+    Launch& L = e->launches[idx];
+    L.is_conv = !(op.kind == OP_INPUT || op.kind == OP_POOL);
+    if (!L.is_conv) return LP_OK;
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
-    if (op.kind == OP_INPUT) return input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
-    if (op.kind == OP_POOL) {
-        const Tensor& t = e->tensors[op.src[0]];
-        return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
-    }
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const ConvShape s = conv_shape(dt, op.cfg, ks, stv);
-    ConvArgs a;
+    ConvArgs& a = L.a;
     memset(&a, 0, sizeof(a));
     a.nsrc = op.nsrc;
     for (int i = 0; i < op.nsrc; ++i) { a.src[i].ptr = tptr(op.src[i]); a.src[i].cs = e->tensors[op.src[i]].cs; }
@@ -467,6 +490,7 @@ static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float*
     a.Ho = stv == 2 ? s0.h / 2 : s0.h;
     a.Wo = stv == 2 ? s0.w / 2 : s0.w;
     conv_pick_tile(s, ks, stv, a.Ho, a.Wo, &a.TH, &a.TW);
+    a.hpitch = conv_pick_pitch(s, dt, ks, stv, a.TH, a.TW);
     a.tiles_x = ceil_div(a.Wo, a.TW);
     a.tiles_y = ceil_div(a.Ho, a.TH);
     a.nct = op.nct;
@@ -483,22 +507,40 @@ static int run_op(lp_engine* e, const Op& op, const void* x, int x_dtype, float*
         a.out_img_stride = (long long)d.h * d.w * d.cs;
         if (op.res >= 0) { a.res = tptr(op.res); a.res_cs = e->tensors[op.res].cs; }
     } else {
-        if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
-        const long long row0 = e->level_off[op.level];
+        a.out = nullptr;   // patched per call: pred + pred_off
+        L.pred_off = (long long)e->level_off[op.level] * LP_PRED_COLS + (op.mode == MODE_PRED ? 13 : 0);
         a.out_pix_stride = LP_PRED_COLS;
         a.out_img_stride = (long long)e->n_anchors * LP_PRED_COLS;
-        if (op.mode == MODE_PRED) {
-            a.out = pred + row0 * LP_PRED_COLS + 13;
-            a.out_c = op.cout;
-        } else {
-            a.out = pred + row0 * LP_PRED_COLS;
-            a.out_c = op.cout;
+        a.out_c = op.cout;
+        if (op.mode == MODE_DECODE) {
             a.reg_bins = op.reg_bins;
             a.proj = op.proj.empty() ? nullptr : (const float*)(e->dev_w + op.proj_off);
             a.stride_px = (float)(8 << op.level);
         }
     }
-    return conv_launch(dt, op.cfg, op.mode, ks, stv, op.nbuf, a, st);
+    L.cfg = op.cfg;
+    L.mode = op.mode;
+    L.ks = ks;
+    L.st = stv;
+    L.nbuf = op.nbuf;
+    return LP_OK;
+}
+
+static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* pred, hipStream_t st) {
+    const Op& op = e->ops[idx];
+    const int dt = e->dtype;
+    auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
+    if (op.kind == OP_INPUT) return input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
+    if (op.kind == OP_POOL) {
+        const Tensor& t = e->tensors[op.src[0]];
+        return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
+    }
+    const Launch& L = e->launches[idx];
+    if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
+    if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
+    ConvArgs a = L.a;
+    a.out = pred + L.pred_off;
+    return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
 }
 
 static int check_ready(const lp_engine* e, const void* x, int x_dtype) {
@@ -513,8 +555,8 @@ static int check_ready(const lp_engine* e, const void* x, int x_dtype) {
 extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
     int rc = check_ready(e, x, x_dtype);
     if (rc) return rc;
-    for (const Op& op : e->ops) {
-        rc = run_op(e, op, x, x_dtype, pred, (hipStream_t)stream);
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        rc = run_op(e, i, x, x_dtype, pred, (hipStream_t)stream);
         if (rc) return rc;
     }
     return LP_OK;
@@ -537,7 +579,7 @@ extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float
     for (int r = 0; r < reps; ++r) {
         LP_HIP_CHECK(hipEventRecord(e->events[0], st));
         for (size_t i = 0; i < n; ++i) {
-            rc = run_op(e, e->ops[i], x, x_dtype, pred, st);
+            rc = run_op(e, i, x, x_dtype, pred, st);
             if (rc) return rc;
             LP_HIP_CHECK(hipEventRecord(e->events[i + 1], st));
         }
@@ -548,5 +590,60 @@ extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float
             op_ms[i] += ms / reps;
         }
     }
+    return LP_OK;
+}
+
+// Per-layer choice of the conv kernel variant for the bound shape: every variant that shares the op's weight
+// packing (same cout tile) is timed in place with hipEvent pairs and the fastest is kept.  The op graph is run
+// once first so that every op sees valid inputs; ops rewrite their own outputs with identical values.
+extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    if (reps < 1) reps = 3;
+    hipStream_t st = (hipStream_t)stream;
+    rc = lp_engine_forward(e, x, x_dtype, pred, stream);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    LP_HIP_CHECK(hipEventCreate(&e0));
+    LP_HIP_CHECK(hipEventCreate(&e1));
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        Op& op = e->ops[i];
+        if (!e->launches[i].is_conv || op.mode != MODE_ACT) continue;
+        const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
+        int best_cfg = op.cfg, best_nb = op.nbuf;
+        float best_ms = -1.f;
+        for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
+            if (conv_shape(e->dtype, cfg, 1, 1).CB != cb) continue;
+            for (int nb = 1; nb <= (cfg == CFG_C ? 1 : 2); ++nb) {
+                op.cfg = cfg;
+                op.nbuf = nb;
+                if (prepare_op(e, i) != LP_OK) continue;
+                if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;   // warm
+                LP_HIP_CHECK(hipEventRecord(e0, st));
+                for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
+                LP_HIP_CHECK(hipEventRecord(e1, st));
+                LP_HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                LP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (best_ms < 0.f || ms < best_ms) { best_ms = ms; best_cfg = cfg; best_nb = nb; }
+            }
+        }
+        op.cfg = best_cfg;
+        op.nbuf = best_nb;
+        rc = prepare_op(e, i);
+        if (rc) return rc;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<std::pair<int, int>> choice;
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf});
+    e->tuned[{e->B, e->H, e->W}] = choice;
+    return LP_OK;
+}
+
+extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
+    if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
+    if (cfg) *cfg = e->ops[op].cfg;
+    if (nbuf) *nbuf = e->ops[op].nbuf;
     return LP_OK;
 }

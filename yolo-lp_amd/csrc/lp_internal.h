@@ -28,7 +28,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- conv launch description ----------------------------------------------------------------------
 enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
-enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/ };
+enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*128 x 256, 4 waves of 128x64*/, CFG_COUNT = 5 };
 
 struct ConvSrc {
     const void* ptr;
@@ -49,6 +49,7 @@ struct ConvArgs {
     int B, H, W;            // input spatial dims
     int Ho, Wo;             // conv output dims (before out_scale)
     int TH, TW, tiles_x, tiles_y;
+    int hpitch;             // LDS row pitch of the staged halo, in pixels (>= (TW-1)*stride + ksize)
     int nct;                // cout tiles
     int out_c;              // channels to store (multiple of the 16-B granule for MODE_ACT)
     long long out_img_stride;  // elements
@@ -64,11 +65,14 @@ struct ConvArgs {
 };
 
 struct ConvShape {  // compile-time geometry of one kernel configuration, mirrored on the host
-    int CB, PB, KC, HPMAX, NT;
+    int CB, PB, KC, HPMAX, NT, WP, WGC, WGP;
 };
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride);
 // Picks the output tile (TH x TW <= PB output pixels, halo <= HPMAX) that needs the fewest blocks.
 void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW);
+// Halo row pitch (>= halo width) that minimises ds_read_b128 bank conflicts of the pixel-operand reads, found by
+// simulating the LDS banking of every fragment read of the tile (exact model: MI355X_MICROARCH.md, LDS table).
+int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------

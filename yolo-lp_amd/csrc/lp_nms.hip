@@ -61,84 +61,101 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
-// One wave per anchor row; a block of 4 waves walks rows with a grid stride.
+// Rotate-within-16-lanes DPP move (row_ror:n): lane j of each 16-lane row receives lane (j - n) mod 16.
+template <int N> __device__ __forceinline__ float ror16f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N> __device__ __forceinline__ int ror16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
+
+// 16 lanes per anchor row, 4 rows per wave, 16 rows per block iteration.  Lane j of a row group owns columns
+// j, j+16, ...: it folds its own columns of each head in ascending order (first maximum wins), then four
+// rotate steps (1,2,4,8) of a (value, index) max-combine leave every lane of the group with the head's result
+// (the combine is commutative, associative and idempotent, so a rotate all-reduce is exact).
 __global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, int B, int N, float conf_f,
                                                    float* __restrict__ rows, unsigned long long* __restrict__ keys,
                                                    int32_t* __restrict__ cnt, int NP) {
-    const int lane = threadIdx.x & 63;
+    constexpr int NK = (NCOL + 15) / 16;   // 19 column slots per lane
+    const int j = threadIdx.x & 15;
     const long long nrows = (long long)B * N;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long wstride = (long long)gridDim.x * 4;
-    for (long long row = wave0; row < nrows; row += wstride) {
+    const long long gstride = (long long)gridDim.x * 16;
+    for (long long base = (long long)blockIdx.x * 16; base < nrows; base += gstride) {   // block-uniform trip count
+        const long long row0 = base + (threadIdx.x >> 4);
+        const bool live = row0 < nrows;                 // whole 16-lane groups are live or not
+        const long long row = live ? row0 : nrows - 1;  // dead groups shadow the last row and write nothing
         float* x = pred + row * NCOL;
-        float v[5];
+        float v[NK];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = lane + 64 * k;
+        for (int k = 0; k < NK; ++k) {
+            const int c = j + 16 * k;
             v[k] = c < NCOL ? x[c] : 0.f;
         }
-        const float obj = __shfl(v[0], 4);
+        const float obj = __shfl(v[0], 4, 16);
         // conf = obj_conf * cls_conf, in place (nms.py:76); obj == 1 leaves the bits unchanged: no store needed
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = lane + 64 * k;
+        for (int k = 0; k < NK; ++k) {
+            const int c = j + 16 * k;
             if (c >= 13 && c < NCOL) {
                 v[k] = v[k] * obj;
-                if (obj != 1.0f) x[c] = v[k];
+                if (obj != 1.0f && live) x[c] = v[k];
             }
         }
         float cf[8];
         int ci[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int a = c_seg[s], b = c_seg[s + 1];
+            constexpr int SEGS[9] = {13, 44, 68, 105, 142, 179, 216, 253, 290};
+            const int a = SEGS[s], b = SEGS[s + 1];
             float bv = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int c = lane + 64 * k;
-                if (c >= a && c < b) { bv = v[k]; bi = c - a; }  // a lane owns at most one column of a group (< 64 wide)
+            for (int k = 0; k < NK; ++k) {
+                if (16 * k + 15 < a || 16 * k >= b) continue;            // compile-time: slot k cannot touch head s
+                const int c = j + 16 * k;
+                if (c >= a && c < b && v[k] > bv) { bv = v[k]; bi = c - a; }   // ascending columns: first maximum stays
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                argmax_combine(bv, bi, ov, oi);
-            }
+            { const float ov = ror16f<1>(bv); const int oi = ror16i<1>(bi); argmax_combine(bv, bi, ov, oi); }
+            { const float ov = ror16f<2>(bv); const int oi = ror16i<2>(bi); argmax_combine(bv, bi, ov, oi); }
+            { const float ov = ror16f<4>(bv); const int oi = ror16i<4>(bi); argmax_combine(bv, bi, ov, oi); }
+            { const float ov = ror16f<8>(bv); const int oi = ror16i<8>(bi); argmax_combine(bv, bi, ov, oi); }
             cf[s] = bv;
             ci[s] = bi;
         }
         float m = cf[0] + cf[1]; m = m + cf[2]; m = m + cf[3]; m = m + cf[4]; m = m + cf[5];
         m = m + cf[6]; m = m + cf[6]; m = m / 8.0f;
-        if (!(m >= conf_f)) continue;   // wave-uniform
+        const bool pass = live && (m >= conf_f);        // uniform inside a 16-lane group
         float sc = cf[0] + cf[1]; sc = sc + cf[2]; sc = sc + cf[3]; sc = sc + cf[4]; sc = sc + cf[5];
         sc = sc + cf[6]; sc = sc + cf[7]; sc = sc / 8.0f;
 
-        const float cx = __shfl(v[0], 0), cy = __shfl(v[0], 1), bw = __shfl(v[0], 2), bh = __shfl(v[0], 3);
-        const float corner = __shfl(v[0], (lane + 1) & 63);   // lanes 4..11 pick columns 5..12
-        float o;
-        if (lane == 0) o = cx - bw / 2;
-        else if (lane == 1) o = cy - bh / 2;
-        else if (lane == 2) o = cx + bw / 2;
-        else if (lane == 3) o = cy + bh / 2;
-        else if (lane < 12) o = corner;
-        else {
-            const int s = (lane - 12) & 7;
-            float fv = cf[0];
-            int iv = ci[0];
+        // all lanes take part in the shuffles; only passing groups store
+        const float cx = __shfl(v[0], 0, 16), cy = __shfl(v[0], 1, 16), bw = __shfl(v[0], 2, 16), bh = __shfl(v[0], 3, 16);
+        const float corner = __shfl(v[0], (j + 1) & 15, 16);      // lanes 4..11 pick columns 5..12
+        if (pass) {
+            float o0, o1;
+            if (j == 0) o0 = cx - bw / 2;
+            else if (j == 1) o0 = cy - bh / 2;
+            else if (j == 2) o0 = cx + bw / 2;
+            else if (j == 3) o0 = cy + bh / 2;
+            else if (j < 12) o0 = corner;
+            else { o0 = cf[0]; if (j == 13) o0 = cf[1]; if (j == 14) o0 = cf[2]; if (j == 15) o0 = cf[3]; }
+            // second element: detection column 16 + j  (conf 4..7 for j < 4, indices 0..7 for 4 <= j < 12)
+            o1 = cf[4];
+            if (j == 1) o1 = cf[5];
+            if (j == 2) o1 = cf[6];
+            if (j == 3) o1 = cf[7];
 #pragma unroll
-            for (int k = 1; k < 8; ++k)
-                if (s == k) { fv = cf[k]; iv = ci[k]; }
-            o = lane < 20 ? fv : (float)iv;
-        }
-        const int b = (int)(row / N), n = (int)(row - (long long)b * N);
-        if (lane < NDET) rows[row * NDET + lane] = o;
-        if (lane == 0) {
-            unsigned u = __float_as_uint(sc);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable bits
-            const unsigned long long key = ((unsigned long long)(~u) << 32) | (unsigned)n;  // ascending key = descending score, then index
-            const int pos = atomicAdd(&cnt[b], 1);
-            keys[(long long)b * NP + pos] = key;
+            for (int k = 0; k < 8; ++k)
+                if (j == 4 + k) o1 = (float)ci[k];
+            float* out = rows + row * NDET;
+            out[j] = o0;
+            if (j < 12) out[16 + j] = o1;
+            if (j == 0) {
+                const int bimg = (int)(row / N), n = (int)(row - (long long)bimg * N);
+                unsigned u = __float_as_uint(sc);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable bits
+                const unsigned long long key = ((unsigned long long)(~u) << 32) | (unsigned)n;  // descending score, then index
+                const int pos = atomicAdd(&cnt[bimg], 1);
+                keys[(long long)bimg * NP + pos] = key;
+            }
         }
     }
 }
@@ -304,7 +321,7 @@ extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_t
 
     LP_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st));
     const long long nrows = (long long)B * N;
-    long long blocks = (nrows + 3) / 4;
+    long long blocks = (nrows + 15) / 16;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, B, N, conf_f, w.rows, w.keys, w.cnt, w.NP);
     hipLaunchKernelGGL(sort_kernel, dim3((unsigned)B), dim3(1024), 0, st, w.keys, w.cnt, w.NP);

@@ -11,6 +11,7 @@ the same formulas, without touching the caller's model.
 """
 import copy
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -73,6 +74,8 @@ class Engine:
         self.arena = None
         self.weights = None
         self.neck_ids = []
+        self.tuned = set()         # (B, H, W) shapes whose per-layer kernel variants were autotuned
+        self.autotune = os.environ.get('LP_AUTOTUNE', '1') != '0'
         self.input_id = self.tensor(3, 0)
         abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
 
@@ -300,6 +303,12 @@ class Engine:
         with torch.cuda.device(self.device):
             self.bind(B, H, W)
             pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
+            if self.autotune and self.bound not in self.tuned:
+                # first batch of this shape: time the kernel variants of every conv layer in place, keep the best
+                abi.check(self.lib.lp_engine_autotune(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
+                                                      ctypes.c_void_p(pred.data_ptr()), self._stream(), 3),
+                          'lp_engine_autotune')
+                self.tuned.add(self.bound)
             abi.check(self.lib.lp_engine_forward(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
                                                  ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
         return pred
@@ -322,8 +331,11 @@ class Engine:
             fl, by = ctypes.c_double(), ctypes.c_double()
             abi.check(self.lib.lp_engine_op_info(self.h, i, ctypes.byref(kind), ctypes.byref(ks), ctypes.byref(cin),
                                                  ctypes.byref(cout), ctypes.byref(fl), ctypes.byref(by)), 'lp_engine_op_info')
+            cfg, nb = ctypes.c_int(), ctypes.c_int()
+            self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box')[kind.value], ksize=ks.value,
-                            cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i])))
+                            cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
+                            variant='%s%d' % ('ABCDE'[cfg.value], nb.value)))
         return ops
 
 
