@@ -202,3 +202,31 @@ def test_nms_rejects_bad_arguments():
         nms_padded(torch.zeros(1, 8, 100, device='cuda'), 0.4, 0.45, 10)
     out = non_max_suppression(torch.zeros(2, 0, 290, device='cuda'))
     assert [tuple(o.shape) for o in out] == [(0, 28), (0, 28)]
+
+
+def test_infer_entry_point_on_gpu(tmp_path, monkeypatch):
+    """tools/infer.py::run on the GPU (fp32 engine) reproduces its own CPU path: same detections after the
+    reference's rescale + round (coordinates may flip by one pixel at a rounding boundary)."""
+    import sys
+    import importlib
+    import numpy as np
+    from PIL import Image
+    from yolov6.utils.synth import build_synthetic
+    monkeypatch.chdir(REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    infer = importlib.import_module('infer')
+    m = build_synthetic(CFG('yololps'), width=0.0625, sigma=1.5)
+    ckpt = tmp_path / 'tiny.pt'
+    torch.save({'model': m.half(), 'ema': None}, str(ckpt))
+    (tmp_path / 'imgs').mkdir()
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (1160, 720, 3), dtype=np.uint8)).save(str(tmp_path / 'imgs' / 'a.png'))
+    kw = dict(weights=str(ckpt), source=str(tmp_path / 'imgs'), yaml=None, img_size=[640, 640], conf_thres=0.06,
+              iou_thres=0.45, max_det=50, save_txt=False, not_save_img=True)
+    cpu = infer.run(device='cpu', save_dir=str(tmp_path / 'o1'), half=False, **kw)[0]
+    gpu = infer.run(device='0', save_dir=str(tmp_path / 'o2'), half=False, **kw)[0]
+    assert gpu.is_cuda and gpu.shape == cpu.shape and len(cpu) > 0
+    assert float((gpu.cpu()[:, :12] - cpu[:, :12]).abs().max()) <= 1.0
+    assert torch.equal(gpu.cpu()[:, 20:], cpu[:, 20:])               # the eight arg-max indices
+    half = infer.run(device='0', save_dir=str(tmp_path / 'o3'), half=True, **kw)[0]
+    assert half.shape[1] == 28

@@ -1,0 +1,99 @@
+"""``Evaler``: batched model + NMS with the reference's three timers (host-side mirror of reference
+yolov6/core/evaler.py:67-151, 507-513, 578-608).
+
+``predict`` is a caller of the hot path and keeps the reference's protocol: pre-process (to device, cast,
+/255), inference (``outputs, _ = model(imgs)``), NMS (``multi_label=True``, max_det 300), each bracketed by
+``time_sync``.  The LP accuracy metric loops (reference :153-283) are CPU bookkeeping outside the hot-path
+scope and are not mirrored: ``eval`` reports the speed figures only.
+"""
+import os
+
+import torch
+
+from yolov6.utils.events import LOGGER
+from yolov6.utils.checkpoint import load_checkpoint
+from yolov6.utils.nms import non_max_suppression
+from yolov6.utils.torch_utils import time_sync, get_model_info
+
+
+class Evaler:
+    def __init__(self, data, batch_size=32, img_size=640, conf_thres=0.03, iou_thres=0.65, device='', half=True,
+                 save_dir='', **unused):
+        self.data = data
+        self.batch_size = batch_size
+        self.img_size = img_size
+        self.conf_thres = conf_thres
+        self.iou_thres = iou_thres
+        self.device = device
+        self.half = half
+        self.save_dir = save_dir
+
+    def init_model(self, model, weights, task):
+        if task != 'train':
+            model = load_checkpoint(weights, map_location=self.device)
+            self.stride = int(model.stride.max())
+            from yolov6.layers.common import RepVGGBlock
+            for layer in model.modules():
+                if isinstance(layer, RepVGGBlock):
+                    layer.switch_to_deploy()
+            LOGGER.info("Switch model to deploy modality.")
+            LOGGER.info("Model Summary: {}".format(get_model_info(model, self.img_size)))
+        model.half() if self.half else model.float()
+        if task != 'train' and self.device.type != 'cpu':   # warm-up on the final dtype: builds + tunes the engine
+            model(torch.zeros(1, 3, self.img_size, self.img_size).to(self.device).type_as(next(model.parameters())))
+        return model
+
+    def predict(self, model, dataloader, task):
+        """dataloader yields (imgs uint8 [B,3,H,W], targets, paths, shapes); returns the per-batch detections."""
+        self.speed_result = torch.zeros(4, device=self.device)
+        pred_results = []
+        for imgs, targets, paths, shapes in dataloader:
+            t1 = time_sync()
+            imgs = imgs.to(self.device, non_blocking=True)
+            imgs = imgs.half() if self.half else imgs.float()
+            imgs /= 255
+            self.speed_result[1] += time_sync() - t1
+            t2 = time_sync()
+            outputs, _ = model(imgs)
+            self.speed_result[2] += time_sync() - t2
+            t3 = time_sync()
+            outputs = non_max_suppression(outputs, self.conf_thres, self.iou_thres, multi_label=True)
+            self.speed_result[3] += time_sync() - t3
+            self.speed_result[0] += len(outputs)
+            pred_results.append(outputs)
+        return pred_results
+
+    def eval_speed(self, task):
+        """ms per image for pre-process / inference / NMS, like the reference's --task speed report."""
+        n_samples = max(self.speed_result[0].item(), 1)
+        pre_time, inf_time, nms_time = (1000 * self.speed_result[1:].cpu().numpy() / n_samples).tolist()
+        for n, v in zip(["pre-process", "inference", "NMS"], [pre_time, inf_time, nms_time]):
+            LOGGER.info("Average {} time: {:.2f} ms".format(n, v))
+        return pre_time, inf_time, nms_time
+
+    @staticmethod
+    def check_task(task):
+        if task not in ['train', 'val', 'test', 'speed']:
+            raise Exception("task argument error: only support 'train' / 'val' / 'test' / 'speed' task.")
+
+    @staticmethod
+    def check_thres(conf_thres, iou_thres, task):
+        if task in ('val', 'test'):
+            if conf_thres > 0.03:
+                LOGGER.warning(f'The best conf_thresh when evaluate the model is less than 0.03, while you set it to: {conf_thres}')
+            if iou_thres != 0.65:
+                LOGGER.warning(f'The best iou_thresh when evaluate the model is 0.65, while you set it to: {iou_thres}')
+        if task == 'speed' and conf_thres < 0.4:
+            LOGGER.warning(f'The best conf_thresh when test the speed of the model is larger than 0.4, while you set it to: {conf_thres}')
+
+    @staticmethod
+    def reload_device(device, model, task):
+        if task == 'train':
+            return next(model.parameters()).device
+        if device == 'cpu':
+            os.environ['CUDA_VISIBLE_DEVICES'] = '-1'
+        elif device:
+            os.environ['CUDA_VISIBLE_DEVICES'] = device
+            assert torch.cuda.is_available()
+        cuda = device != 'cpu' and torch.cuda.is_available()
+        return torch.device('cuda:0' if cuda else 'cpu')
