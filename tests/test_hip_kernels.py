@@ -187,3 +187,23 @@ def test_head(dtype, bins):
     assert float((pred[..., 13:] - ref[..., 13:]).abs().max()) <= tol * 2            # probabilities
     scale = float(ref[..., :13].abs().max())
     assert float((pred[..., :13] - ref[..., :13]).abs().max()) <= tol * scale * (4 if bins > 1 else 2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('xdtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('cout,H,W', [(32, 64, 96), (16, 128, 64), (48, 32, 32)])
+def test_fused_stem(dtype, xdtype, cout, H, W):
+    """3x3 s2 conv reading the caller's NCHW image directly (stem_kernel)."""
+    from yolov6.hip import abi
+    eng = _engine(dtype)
+    wt = _rand((cout, 3, 3, 3), 1, (2.0 / 27) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    dst = eng.conv([eng.input_id], wt, bias, 3, 2, abi.LP_ACT_RELU, 0)
+    eng.finish()
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(3)).to(xdtype)
+    eng.forward(x.cuda())
+    got = eng.tensor_view(dst).float().cpu()
+    q = lambda t: t.float().to(dtype).float()
+    ref = F.relu(F.conv2d(q(x), q(wt), bias, stride=2, padding=1))
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= TOL[dtype]

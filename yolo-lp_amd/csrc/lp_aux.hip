@@ -51,6 +51,63 @@ int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H,
     return fail(LP_ERR_ARG, "input: x dtype");
 }
 
+// ---- input, space-to-depth form: NCHW [B,3,H,W] -> NHWC [B,H/2,W/2,16] with channel (py*2+px)*3 + c holding
+// x[c][2Y+py][2X+px] (12 real + 4 zero channels).  A 3x3 stride-2 conv of the image is then a stride-1 conv on this
+// tensor (taps (dy,py): (0,1)->ky 0, (1,0)->ky 1, (1,1)->ky 2; the third tap row/column has zero weights), which
+// runs on the stride-1 path of the MFMA kernel with a quarter of the halo.  One thread per output pixel: six
+// coalesced 2-element reads, one 32-byte (fp32: 64-byte) row write.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void input_s2d_kernel(const TI* __restrict__ x, TO* __restrict__ dst, int B, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo, HW = (long long)H * W;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int X = (int)(i % Wo);
+        const long long t = i / Wo;
+        const int Y = (int)(t % Ho);
+        const long long b = t / Ho;
+        TO row[16] __attribute__((aligned(16)));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const TI* p = x + (b * 3 + c) * HW + (long long)(2 * Y + py) * W + 2 * X;
+                row[(py * 2 + 0) * 3 + c] = (TO)(float)p[0];
+                row[(py * 2 + 1) * 3 + c] = (TO)(float)p[1];
+            }
+#pragma unroll
+        for (int k = 12; k < 16; ++k) row[k] = (TO)0.f;
+        uint4* o = (uint4*)(dst + i * 16);
+        const uint4* rv = (const uint4*)row;
+#pragma unroll
+        for (int k = 0; k < (int)(16 * sizeof(TO) / 16); ++k) o[k] = rv[k];
+    }
+}
+
+template <typename TI>
+static int input_s2d_launch_to(const void* x, void* dst, int dtype, int B, int H, int W, hipStream_t st) {
+    long long blocks = ((long long)B * (H / 2) * (W / 2) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks);
+    switch (dtype) {
+        case LP_F16: hipLaunchKernelGGL((input_s2d_kernel<TI, f16>), grid, dim3(256), 0, st, (const TI*)x, (f16*)dst, B, H, W); break;
+        case LP_BF16: hipLaunchKernelGGL((input_s2d_kernel<TI, bf16>), grid, dim3(256), 0, st, (const TI*)x, (bf16*)dst, B, H, W); break;
+        case LP_F32: hipLaunchKernelGGL((input_s2d_kernel<TI, float>), grid, dim3(256), 0, st, (const TI*)x, (float*)dst, B, H, W); break;
+        default: return fail(LP_ERR_ARG, "input: dtype");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("input launch: ") + hipGetErrorString(e));
+    return LP_OK;
+}
+
+int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st) {
+    switch (x_dtype) {
+        case LP_F16: return input_s2d_launch_to<f16>(x, dst, dtype, B, H, W, st);
+        case LP_BF16: return input_s2d_launch_to<bf16>(x, dst, dtype, B, H, W, st);
+        case LP_F32: return input_s2d_launch_to<float>(x, dst, dtype, B, H, W, st);
+    }
+    return fail(LP_ERR_ARG, "input: x dtype");
+}
+
 // ---- SPPF pool chain: y1 = m(x), y2 = m(y1), y3 = m(y2) with m = 5x5 stride-1 pad-2 max pool
 // (yolov6/layers/common.py:144-146).  One block owns (image, 8-channel group): the whole h x w plane of the
 // group lives in LDS and each pool is a separable row pass + column pass (max is exact in every dtype, so

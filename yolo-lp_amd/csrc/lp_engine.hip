@@ -23,6 +23,7 @@ enum OpKind { OP_INPUT = 0, OP_CONV = 1, OP_DECONV = 2, OP_POOL = 3, OP_HEAD_CLS
 
 struct Tensor {
     int c, cs, sl;     // logical channels, stored channels, log2 downscale
+    bool unused = false;  // declared by the host but no longer read or written (not placed in the arena)
     size_t offset;     // bytes inside the arena (valid after bind)
     int h, w;
 };
@@ -38,6 +39,7 @@ struct Op {
     int cout = 0;        // logical output channels
     int cin = 0;         // logical input channels (sum over sources)
     int level = 0, reg_bins = 1;
+    bool s2d = false;    // input op writes the space-to-depth form (see lp_engine_finalize)
     std::vector<float> weight, bias, proj;  // host fp32, reference layouts
     // filled by finalize
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1;
@@ -272,6 +274,40 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
     blob.clear();
     blob.resize(256, 0);   // zero page: DMA source for padding granules (ConvArgs::zero)
     auto align = [&]() { blob.resize((blob.size() + 255) / 256 * 256, 0); };
+    // Stem rewrite: a 3x3 stride-2 conv that is the only reader of the network input becomes a 3x3 stride-1 conv over
+    // the space-to-depth form of the image (input_s2d_kernel): same sums, a quarter of the halo, no K=27 special case.
+    if (e->ops.size() > 1 && getenv("LP_NO_STEM_S2D") == nullptr) {
+        Op& c = e->ops[1];
+        const int in_id = e->ops[0].dst;
+        bool only_reader = c.kind == OP_CONV && c.ksize == 3 && c.stride == 2 && c.nsrc == 1 && c.src[0] == in_id && c.res < 0;
+        for (size_t i = 2; i < e->ops.size() && only_reader; ++i) {
+            const Op& o = e->ops[i];
+            for (int k = 0; k < o.nsrc; ++k) only_reader &= o.src[k] != in_id;
+            only_reader &= o.res != in_id;
+        }
+        if (only_reader) {
+            Tensor t;
+            t.c = 12; t.cs = 16; t.sl = 1; t.offset = 0; t.h = t.w = 0;
+            e->tensors.push_back(t);
+            const int s2d_id = (int)e->tensors.size() - 1;
+            e->tensors[in_id].unused = true;
+            e->ops[0].s2d = true;
+            e->ops[0].dst = s2d_id;
+            std::vector<float> w2((size_t)c.cout * 12 * 9, 0.f);
+            for (int co = 0; co < c.cout; ++co)
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int dy = ky == 0 ? 0 : 1, py = ky == 1 ? 0 : 1;   // image row 2*oy-1+ky = 2*(oy-1+dy) + py
+                            const int dx = kx == 0 ? 0 : 1, px = kx == 1 ? 0 : 1;
+                            w2[(((size_t)co * 12 + (py * 2 + px) * 3 + ch) * 3 + dy) * 3 + dx] = c.weight[(((size_t)co * 3 + ch) * 3 + ky) * 3 + kx];
+                        }
+            c.weight.swap(w2);
+            c.src[0] = s2d_id;
+            c.stride = 1;
+            c.cin = 12;
+        }
+    }
     for (Op& op : e->ops) {
         if (op.kind == OP_INPUT || op.kind == OP_POOL) continue;
         const int ks = op.kind == OP_CONV ? op.ksize : 1;
@@ -376,7 +412,7 @@ static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>
         t.h = H >> t.sl;
         t.w = W >> t.sl;
         t.offset = off;
-        off += ((size_t)B * t.h * t.w * t.cs * esz + 255) / 256 * 256;
+        if (!t.unused) off += ((size_t)B * t.h * t.w * t.cs * esz + 255) / 256 * 256;
         if (out) (*out)[i] = t;
     }
     return off + 256;
@@ -439,7 +475,7 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
     const Tensor& s0 = e->tensors[op.kind == OP_INPUT ? op.dst : op.src[0]];
     const double in_px = (double)e->B * s0.h * s0.w;
     switch (op.kind) {
-        case OP_INPUT: by = in_px * 3 * 4 + tbytes(op.dst); break;
+        case OP_INPUT: by = (double)e->B * e->H * e->W * 3 * esz + tbytes(op.dst); break;
         case OP_CONV: {
             const Tensor& d = e->tensors[op.dst];
             fl = 2.0 * e->B * d.h * d.w * op.cout * op.cin * op.ksize * op.ksize;
@@ -530,7 +566,9 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     const Op& op = e->ops[idx];
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
-    if (op.kind == OP_INPUT) return input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
+    if (op.kind == OP_INPUT)
+        return op.s2d ? input_s2d_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st)
+                      : input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
     if (op.kind == OP_POOL) {
         const Tensor& t = e->tensors[op.src[0]];
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);

@@ -77,6 +77,7 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, c
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
+int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
 int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B, int h, int w, int cs, hipStream_t st);
 
 }  // namespace lp

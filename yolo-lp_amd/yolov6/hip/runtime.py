@@ -333,7 +333,7 @@ class Engine:
                                                  ctypes.byref(cout), ctypes.byref(fl), ctypes.byref(by)), 'lp_engine_op_info')
             cfg, nb = ctypes.c_int(), ctypes.c_int()
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
-            ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box')[kind.value], ksize=ks.value,
+            ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
                             variant='%s%d' % ('ABCDE'[cfg.value], nb.value)))
         return ops
