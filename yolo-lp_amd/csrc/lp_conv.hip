@@ -71,21 +71,34 @@ int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH
     return best;
 }
 
-void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW) {
-    long best_cost = -1;
-    int bh = 1, bw = 1;
-    for (int th = 1; th <= s.PB && th <= Ho + 0; ++th) {
+// Candidate output tiles (TH x TW <= PB pixels, halo <= HPMAX), best first: fewest workgroups, then the smallest
+// halo.  `choice` selects the n-th distinct candidate (clamped) -- the autotuner times the first few.
+void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int choice, int* TH, int* TW) {
+    struct Cand { long cost; int th, tw; };
+    Cand best[4];
+    int n = 0;
+    for (int th = 1; th <= s.PB && th <= Ho; ++th) {
         int tw = s.PB / th;
         if (tw > Wo) tw = Wo;
         if (tw < 1) continue;
         const int hh = (th - 1) * stride + ksize, hw = (tw - 1) * stride + ksize;
         if (hh * hw > s.HPMAX) continue;
         const long tiles = (long)ceil_div(Ho, th) * ceil_div(Wo, tw);
-        const long cost = tiles * 100000 + (long)hh * hw;  // fewest blocks first, then the smallest halo
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; bh = th; bw = tw; }
+        Cand c = {tiles * 100000 + (long)hh * hw, th, tw};
+        // insertion into the sorted top-4 (distinct tile counts give distinct costs; equal costs keep the first)
+        int pos = n < 4 ? n : 4;
+        for (int k = 0; k < (n < 4 ? n : 4); ++k)
+            if (c.cost < best[k].cost) { pos = k; break; }
+        if (pos >= 4) continue;
+        for (int k = (n < 4 ? n : 3); k > pos; --k) best[k] = best[k - 1];
+        best[pos] = c;
+        if (n < 4) ++n;
     }
-    *TH = bh;
-    *TW = bw;
+    if (n == 0) { *TH = 1; *TW = 1; return; }
+    if (choice < 0) choice = 0;
+    if (choice >= n) choice = n - 1;
+    *TH = best[choice].th;
+    *TW = best[choice].tw;
 }
 
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {

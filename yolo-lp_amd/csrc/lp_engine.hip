@@ -42,7 +42,7 @@ struct Op {
     bool s2d = false;    // input op writes the space-to-depth form (see lp_engine_finalize)
     std::vector<float> weight, bias, proj;  // host fp32, reference layouts
     // filled by finalize
-    int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1;
+    int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -73,7 +73,7 @@ struct lp_engine {
     std::vector<int> level_off;       // first pred row of each level
     std::vector<hipEvent_t> events;
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
-    std::map<std::vector<int>, std::vector<std::pair<int, int>>> tuned;  // (B,H,W) -> per-op (cfg, nbuf)
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile}
 };
 
 static int prepare_op(lp_engine* e, size_t idx);
@@ -313,7 +313,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         const int ks = op.kind == OP_CONV ? op.ksize : 1;
         const int st = op.kind == OP_CONV ? op.stride : 1;
         int cout_store;
-        if (op.kind == OP_HEAD_CLS) { op.mode = MODE_PRED; op.cfg = CFG_B; cout_store = op.cout; }
+        if (op.kind == OP_HEAD_CLS) { op.mode = MODE_PRED; op.cfg = getenv("LP_PRED_CFG") ? atoi(getenv("LP_PRED_CFG")) : CFG_C; cout_store = op.cout; }
         else if (op.kind == OP_HEAD_BOX) { op.mode = MODE_DECODE; op.cfg = CFG_A; cout_store = op.cout; }
         else {
             op.mode = MODE_ACT;
@@ -442,7 +442,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i].first; e->ops[i].nbuf = it->second[i].second; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -525,8 +525,10 @@ static int prepare_op(lp_engine* e, size_t idx) {
     a.W = s0.w;
     a.Ho = stv == 2 ? s0.h / 2 : s0.h;
     a.Wo = stv == 2 ? s0.w / 2 : s0.w;
-    conv_pick_tile(s, ks, stv, a.Ho, a.Wo, &a.TH, &a.TW);
+    conv_pick_tile(s, ks, stv, a.Ho, a.Wo, op.tile, &a.TH, &a.TW);
     a.hpitch = conv_pick_pitch(s, dt, ks, stv, a.TH, a.TW);
+    a.tw_magic = (unsigned)(((1u << 22) + a.TW - 1) / a.TW);          // n / TW == (n * magic) >> 22 for n * TW < 2^22
+    a.hp_magic = (unsigned)(((1u << 22) + a.hpitch - 1) / a.hpitch);
     a.tiles_x = ceil_div(a.Wo, a.TW);
     a.tiles_y = ceil_div(a.Ho, a.TH);
     a.nct = op.nct;
@@ -648,33 +650,45 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         Op& op = e->ops[i];
         if (!e->launches[i].is_conv || op.mode != MODE_ACT) continue;
         const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
-        int best_cfg = op.cfg, best_nb = op.nbuf;
+        int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile;
         float best_ms = -1.f;
         for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
             if (conv_shape(e->dtype, cfg, 1, 1).CB != cb) continue;
             for (int nb = 1; nb <= (cfg == CFG_C ? 1 : 2); ++nb) {
-                op.cfg = cfg;
-                op.nbuf = nb;
-                if (prepare_op(e, i) != LP_OK) continue;
-                if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;   // warm
-                LP_HIP_CHECK(hipEventRecord(e0, st));
-                for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
-                LP_HIP_CHECK(hipEventRecord(e1, st));
-                LP_HIP_CHECK(hipEventSynchronize(e1));
-                float ms = 0.f;
-                LP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                if (best_ms < 0.f || ms < best_ms) { best_ms = ms; best_cfg = cfg; best_nb = nb; }
+                int last_th = -1, last_tw = -1;
+                for (int tile = 0; tile < 3; ++tile) {
+                    op.cfg = cfg;
+                    op.nbuf = nb;
+                    op.tile = tile;
+                    if (prepare_op(e, i) != LP_OK) continue;
+                    if (e->launches[i].a.TH == last_th && e->launches[i].a.TW == last_tw) break;   // no further candidates
+                    last_th = e->launches[i].a.TH;
+                    last_tw = e->launches[i].a.TW;
+                    if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;   // warm
+                    float ms_min = -1.f;
+                    for (int round = 0; round < 2; ++round) {     // best of two rounds of `reps` launches
+                        LP_HIP_CHECK(hipEventRecord(e0, st));
+                        for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
+                        LP_HIP_CHECK(hipEventRecord(e1, st));
+                        LP_HIP_CHECK(hipEventSynchronize(e1));
+                        float ms = 0.f;
+                        LP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                        if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+                    }
+                    if (best_ms < 0.f || ms_min < best_ms) { best_ms = ms_min; best_cfg = cfg; best_nb = nb; best_tile = tile; }
+                }
             }
         }
         op.cfg = best_cfg;
         op.nbuf = best_nb;
+        op.tile = best_tile;
         rc = prepare_op(e, i);
         if (rc) return rc;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    std::vector<std::pair<int, int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf});
+    std::vector<std::vector<int>> choice;
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }

@@ -49,6 +49,7 @@ struct ConvArgs {
     int B, H, W;            // input spatial dims
     int Ho, Wo;             // conv output dims (before out_scale)
     int TH, TW, tiles_x, tiles_y;
+    unsigned tw_magic, hp_magic;  // multiply-shift reciprocals of TW and hpitch (exact for the index ranges used)
     int hpitch;             // LDS row pitch of the staged halo, in pixels (>= (TW-1)*stride + ksize)
     int nct;                // cout tiles
     int out_c;              // channels to store (multiple of the 16-B granule for MODE_ACT)
@@ -69,7 +70,7 @@ struct ConvShape {  // compile-time geometry of one kernel configuration, mirror
 };
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride);
 // Picks the output tile (TH x TW <= PB output pixels, halo <= HPMAX) that needs the fewest blocks.
-void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int* TH, int* TW);
+void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int choice, int* TH, int* TW);
 // Halo row pitch (>= halo width) that minimises ds_read_b128 bank conflicts of the pixel-operand reads, found by
 // simulating the LDS banking of every fragment read of the tile (exact model: MI355X_MICROARCH.md, LDS table).
 int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
