@@ -116,41 +116,38 @@ int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, in
 template <typename T>
 __global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
                                                         T* __restrict__ d3, int h, int w, int cs) {
+    typedef T V8 __attribute__((ext_vector_type(8)));          // the 8 channels of one pixel: 16 B (fp32: 32 B)
     extern __shared__ __attribute__((aligned(16))) char pool_smem[];
     const int hw = h * w;
-    T* cur = (T*)pool_smem;          // [hw][8]
-    T* tmp = cur + (size_t)hw * 8;   // [hw][8]
+    V8* cur = (V8*)pool_smem;     // [hw]
+    V8* tmp = cur + hw;           // [hw]
     const int groups = cs / 8;
     const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
     const long long base = (long long)b * hw * cs + cg * 8;
-    const int n = hw * 8;
-    for (int i = threadIdx.x; i < n; i += 256) cur[i] = src[base + (long long)(i >> 3) * cs + (i & 7)];
+    auto vmax = [](V8 a, V8 c) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = (float)c[k] > (float)a[k] ? c[k] : a[k];
+        return a;
+    };
+    for (int p = threadIdx.x; p < hw; p += 256) cur[p] = *(const V8*)(src + base + (long long)p * cs);
     __syncthreads();
     T* outs[3] = {d1, d2, d3};
     for (int round = 0; round < 3; ++round) {
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int p = i >> 3, c = i & 7;
+        for (int p = threadIdx.x; p < hw; p += 256) {              // row pass
             const int y = p / w, x = p - y * w;
             const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= w ? w - 1 : x + 2;
-            T m = cur[(y * w + x0) * 8 + c];
-            for (int xx = x0 + 1; xx <= x1; ++xx) {
-                const T v = cur[(y * w + xx) * 8 + c];
-                m = (float)v > (float)m ? v : m;
-            }
-            tmp[i] = m;
+            V8 m = cur[y * w + x0];
+            for (int xx = x0 + 1; xx <= x1; ++xx) m = vmax(m, cur[y * w + xx]);
+            tmp[p] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int p = i >> 3, c = i & 7;
+        for (int p = threadIdx.x; p < hw; p += 256) {              // column pass
             const int y = p / w, x = p - y * w;
             const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= h ? h - 1 : y + 2;
-            T m = tmp[(y0 * w + x) * 8 + c];
-            for (int yy = y0 + 1; yy <= y1; ++yy) {
-                const T v = tmp[(yy * w + x) * 8 + c];
-                m = (float)v > (float)m ? v : m;
-            }
-            outs[round][base + (long long)p * cs + c] = m;
-            cur[i] = m;   // element i is only read by its own row pass peers after the barrier below
+            V8 m = tmp[y0 * w + x];
+            for (int yy = y0 + 1; yy <= y1; ++yy) m = vmax(m, tmp[yy * w + x]);
+            *(V8*)(outs[round] + base + (long long)p * cs) = m;
+            cur[p] = m;   // only read again after the barrier below
         }
         __syncthreads();
     }
