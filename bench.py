@@ -36,9 +36,13 @@ def parse():
     ap.add_argument('--conf', type=float, default=0.4)
     ap.add_argument('--iou', type=float, default=0.45)
     ap.add_argument('--max-det', type=int, default=1000)
+    ap.add_argument('--no-overlap', action='store_true', help='run forward and NMS on one stream (default: NMS of step i on a '
+                    'second stream under the forward of step i+1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
+    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'),
+                    help='per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run (tools/pmc_traffic.py)')
     return ap.parse_args()
 
 
@@ -121,14 +125,26 @@ def main():
     eng = runtime.engine_for(model)
 
     gathered = None
+    # Two HIP streams: the forward of step i+1 (MFMA-bound conv kernels) overlaps the NMS (+ all-gather) of step i
+    # (bandwidth / latency-bound, one workgroup per image in its last two kernels).  Every step still runs the whole
+    # path; pred is a fresh buffer per step, so the stages only meet through the recorded events.
+    overlap = not args.no_overlap
+    s_fwd = torch.cuda.current_stream(dev)
+    s_post = torch.cuda.Stream(dev) if overlap else s_fwd
 
     def step():
         nonlocal gathered
         pred = eng.forward(x)
-        det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
-        if world > 1:
-            gathered = gather_detections(det, count, out=gathered)
-            return gathered
+        if overlap:
+            ready = torch.cuda.Event()
+            ready.record(s_fwd)
+            s_post.wait_event(ready)
+            pred.record_stream(s_post)
+        with torch.cuda.stream(s_post):
+            det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
+            if world > 1:
+                gathered = gather_detections(det, count, out=gathered)
+                return gathered
         return det, count
 
     with torch.no_grad():
@@ -181,12 +197,17 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         total_ms = sum(o['ms'] for o in ops)
+        traffic = None
+        default_workload = (args.model, args.batch, args.size, args.dtype) == ('yololps', 32, 640, 'f16')
+        if default_workload and os.path.exists(args.traffic_file):     # PMC counters come from a separate rocprofv3 pass
+            traffic = json.load(open(args.traffic_file)).get('hbm_bytes_per_launch')
         roofline = {
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': None,
+            'traffic': traffic,
             'kernel': 'conv_mfma_kernel 3x3 (implicit GEMM, all %d launches of a step)' % len(conv3),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
+            'algorithmic_bytes_per_launch': round(sum(o['bytes'] for o in conv3) / max(1, len(conv3))),
             'all_mfma_kernels_tflops': round(sum(o['flops'] for o in allmm) / (sum(o['ms'] for o in allmm) * 1e-3) / 1e12, 2),
             'forward_device_ms': round(total_ms, 3), 'nms_device_ms': round(sorted(t_nms)[len(t_nms) // 2], 3),
             'forward_hbm_gbs': round(sum(o['bytes'] for o in ops) / (total_ms * 1e-3) / 1e9, 1),
@@ -200,6 +221,7 @@ def main():
                                    '(sigma %.2f), conf %.2f iou %.2f max_det %d'
                                    % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
                        'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
+                       'streams': 'forward || NMS(+gather) of the previous step' if overlap else 'single stream',
                        'mean_detections_per_image': round(counts, 1),
                        'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
                        'device_ms_per_step': round(ev0.elapsed_time(ev1) / args.steps, 3)},
