@@ -22,6 +22,7 @@ ap.add_argument('--hw', type=int, default=40, help='feature-map height = width a
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
 ap.add_argument('--dtype', default='f16')
+ap.add_argument('--stamps', action='store_true', help='needs LP_HIP_LIB=yolo-lp_amd/libyololp_hip_stamps.so (make stamps)')
 args = ap.parse_args()
 
 dt = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}[args.dtype]
@@ -34,6 +35,11 @@ w = torch.randn(args.cout, args.cin, args.k, args.k, generator=g) * (2.0 / (args
 dst = eng.conv([src], w, torch.zeros(args.cout), args.k, args.s, abi.LP_ACT_RELU, sl)
 eng.finish()
 H = W = args.hw << sl
+stamps = None
+if args.stamps:
+    import ctypes
+    stamps = torch.zeros(1 << 20, dtype=torch.int64, device='cuda:0')
+    eng.lib.lpdbg_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 eng.bind(args.batch, H, W)
 eng.tensor_view(src).copy_(torch.randn(args.batch, args.cin, args.hw, args.hw, generator=g).to('cuda:0', dt))
 ops = eng.profile(torch.zeros(args.batch, 3, H, W, device='cuda:0', dtype=dt), reps=args.iters)
@@ -41,3 +47,12 @@ o = ops[1]
 print('%s k%d s%d %d->%d @%dx%d B%d variant %s: %.1f us  %.1f TFLOP/s' % (
     args.dtype, args.k, args.s, args.cin, args.cout, args.hw, args.hw, args.batch, o['variant'], o['ms'] * 1e3,
     o['flops'] / o['ms'] / 1e9))
+
+if stamps is not None:
+    st = stamps.view(-1, 8).cpu()
+    st = st[st[:, 7] == 1].double()
+    n = st.shape[0]
+    tot = st[:, 5].mean()
+    print('waves %d, chunks/wave %d, mean wave lifetime %.0f cycles (s_memtime ticks)' % (n, int(st[0, 6]), tot))
+    for name, col in (('top barrier', 0), ('DMA issue', 1), ('DMA wait (vmcnt)', 2), ('data barrier', 3), ('compute', 4)):
+        print('  %-18s %9.0f ticks  %5.1f%%   per chunk %7.0f' % (name, st[:, col].mean(), 100 * st[:, col].mean() / tot, st[:, col].mean() / st[0, 6]))

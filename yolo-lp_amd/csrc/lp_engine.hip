@@ -77,6 +77,8 @@ struct lp_engine {
 };
 
 static int prepare_op(lp_engine* e, size_t idx);
+static unsigned long long* g_stamps = nullptr;
+extern "C" void lpdbg_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }   // debug hook (LP_STAMPS builds)
 static bool valid_tensor(const lp_engine* e, int id) { return id >= 0 && id < (int)e->tensors.size(); }
 
 extern "C" const char* lp_version(void) { return "yololp-hip 0.1 (gfx950)"; }
@@ -556,6 +558,7 @@ static int prepare_op(lp_engine* e, size_t idx) {
             a.stride_px = (float)(8 << op.level);
         }
     }
+    a.stamps = g_stamps;
     L.cfg = op.cfg;
     L.mode = op.mode;
     L.ks = ks;

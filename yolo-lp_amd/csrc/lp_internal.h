@@ -41,6 +41,7 @@ struct ConvArgs {
     int nsrc;
     const void* w;          // packed [phase][cout_tile][chunk][tap][CB][KC]
     const float* bias;      // [phase?][nct*CB]  (same for every phase)
+    unsigned long long* stamps;  // debug builds (-DLP_STAMPS): per-wave phase cycle counters, else null
     const void* zero;       // >= 16 zero bytes: DMA source of out-of-image / out-of-range granules
     void* out;
     const void* res;        // residual (same dtype/geometry as out) or null

@@ -12,7 +12,7 @@ LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
 LP_PRED_COLS, LP_DET_COLS, LP_MAX_SRC = 290, 28, 4
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # .../yolo-lp_amd
-LIB_PATH = os.path.join(_PKG_ROOT, 'libyololp_hip.so')
+LIB_PATH = os.environ.get('LP_HIP_LIB') or os.path.join(_PKG_ROOT, 'libyololp_hip.so')   # LP_HIP_LIB: debug builds
 CSRC_DIR = os.path.join(_PKG_ROOT, 'csrc')
 
 
