@@ -40,6 +40,9 @@ struct Op {
     int cin = 0;         // logical input channels (sum over sources)
     int level = 0, reg_bins = 1;
     bool s2d = false;    // input op writes the space-to-depth form (see lp_engine_finalize)
+    int lane = 0;        // execution lane (HIP stream) hint given by the host: independent branches overlap
+    std::vector<int> deps;   // ops on OTHER lanes whose outputs this op reads (filled by finalize)
+    bool signal = false;     // some op on another lane waits for this one
     std::vector<float> weight, bias, proj;  // host fp32, reference layouts
     // filled by finalize
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
@@ -59,6 +62,9 @@ struct Launch {
 
 using namespace lp;
 
+#ifndef LP_MAX_LANES
+#define LP_MAX_LANES 3
+#endif
 struct lp_engine {
     int dtype = LP_F16;
     bool finalized = false;
@@ -72,10 +78,17 @@ struct lp_engine {
     int B = 0, H = 0, W = 0, n_anchors = 0;
     std::vector<int> level_off;       // first pred row of each level
     std::vector<hipEvent_t> events;
+    int cur_lane = 0;                 // lane assigned to ops added from now on (lp_engine_set_lane)
+    int n_lanes = 1;
+    hipStream_t lane_stream[LP_MAX_LANES] = {nullptr, nullptr, nullptr};   // [0] = the caller's stream
+    std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
+    hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {nullptr, nullptr, nullptr};
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
     std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile}
 };
 
+#define LP_MAX_LANES 3
+struct lp_engine;
 static int prepare_op(lp_engine* e, size_t idx);
 static unsigned long long* g_stamps = nullptr;
 extern "C" void lpdbg_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }   // debug hook (LP_STAMPS builds)
@@ -96,6 +109,9 @@ extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
 extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->op_event) if (ev) (void)hipEventDestroy(ev);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    for (int l = 1; l < LP_MAX_LANES; ++l) { if (e->join_ev[l]) (void)hipEventDestroy(e->join_ev[l]); if (e->lane_stream[l]) (void)hipStreamDestroy(e->lane_stream[l]); }
     delete e;
 }
 
@@ -112,6 +128,13 @@ extern "C" int lp_engine_tensor(lp_engine* e, int channels, int stride_log2) {
     return (int)e->tensors.size() - 1;
 }
 
+extern "C" int lp_engine_set_lane(lp_engine* e, int lane) {
+    if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_set_lane: engine is null or frozen");
+    if (lane < 0 || lane >= LP_MAX_LANES) return fail(LP_ERR_ARG, "lp_engine_set_lane: lane must be 0..2");
+    e->cur_lane = lane;
+    return LP_OK;
+}
+
 extern "C" int lp_engine_add_input(lp_engine* e, int dst) {
     if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_add_input: engine is null or frozen");
     if (!e->ops.empty()) return fail(LP_ERR_STATE, "lp_engine_add_input: must be the first op");
@@ -122,6 +145,7 @@ extern "C" int lp_engine_add_input(lp_engine* e, int dst) {
     op.dst = dst;
     op.cout = 3;
     op.cin = 3;
+    op.lane = e->cur_lane;
     e->ops.push_back(op);
     return LP_OK;
 }
@@ -163,6 +187,7 @@ extern "C" int lp_engine_add_conv(lp_engine* e, const lp_conv_desc* d) {
     op.cin = cin;
     op.weight.assign(d->weight, d->weight + (size_t)op.cout * cin * d->ksize * d->ksize);
     op.bias.assign(d->bias, d->bias + op.cout);
+    op.lane = e->cur_lane;
     e->ops.push_back(op);
     return LP_OK;
 }
@@ -181,6 +206,7 @@ extern "C" int lp_engine_add_deconv2x2(lp_engine* e, int src, int dst, const flo
     op.cout = e->tensors[dst].c;
     op.weight.assign(weight, weight + (size_t)op.cin * op.cout * 4);
     op.bias.assign(bias, bias + op.cout);
+    op.lane = e->cur_lane;
     e->ops.push_back(op);
     return LP_OK;
 }
@@ -203,6 +229,7 @@ extern "C" int lp_engine_add_pool5_chain(lp_engine* e, int src, int dst1, int ds
     op.dst2 = dst2;
     op.dst3 = dst3;
     op.cin = op.cout = e->tensors[src].c;
+    op.lane = e->cur_lane;
     e->ops.push_back(op);
     return LP_OK;
 }
@@ -224,6 +251,7 @@ static int add_head(lp_engine* e, int kind, int src, int level, int cout, int re
     op.weight.assign(weight, weight + (size_t)cout * op.cin);
     op.bias.assign(bias, bias + cout);
     if (proj) op.proj.assign(proj, proj + reg_bins);
+    op.lane = e->cur_lane;
     e->ops.push_back(op);
     return LP_OK;
 }
@@ -308,6 +336,31 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
             c.src[0] = s2d_id;
             c.stride = 1;
             c.cin = 12;
+        }
+    }
+    // Cross-lane dependencies: an op waits for the latest earlier op on another lane that wrote one of the tensors it
+    // reads (RAW) or that read / wrote a tensor it writes (WAR / WAW).  Same-lane order is stream order.
+    if (getenv("LP_SINGLE_LANE")) for (Op& op : e->ops) op.lane = 0;
+    e->n_lanes = 1;
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        Op& op = e->ops[i];
+        if (op.lane + 1 > e->n_lanes) e->n_lanes = op.lane + 1;
+        auto reads = [](const Op& o, int t) { for (int k = 0; k < o.nsrc; ++k) if (o.src[k] == t) return true; return o.res == t; };
+        auto writes = [](const Op& o, int t) { return o.dst == t || o.dst2 == t || o.dst3 == t; };
+        std::vector<int> mine_r, mine_w;
+        for (int k = 0; k < op.nsrc; ++k) mine_r.push_back(op.src[k]);
+        if (op.res >= 0) mine_r.push_back(op.res);
+        for (int t : {op.dst, op.dst2, op.dst3}) if (t >= 0) mine_w.push_back(t);
+        for (int lane = 0; lane < LP_MAX_LANES; ++lane) {
+            if (lane == op.lane) continue;
+            for (size_t j = i; j-- > 0;) {
+                const Op& o = e->ops[j];
+                if (o.lane != lane) continue;
+                bool hit = false;
+                for (int t : mine_r) hit |= writes(o, t);
+                for (int t : mine_w) hit |= writes(o, t) || reads(o, t);
+                if (hit) { op.deps.push_back((int)j); e->ops[j].signal = true; break; }   // the latest one covers the earlier ones
+            }
         }
     }
     for (Op& op : e->ops) {
@@ -595,11 +648,55 @@ static int check_ready(const lp_engine* e, const void* x, int x_dtype) {
     return LP_OK;
 }
 
+static int ensure_lanes(lp_engine* e) {
+    for (int l = 1; l < e->n_lanes; ++l)
+        if (!e->lane_stream[l]) LP_HIP_CHECK(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
+    if (!e->fork_ev) LP_HIP_CHECK(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+    for (int l = 1; l < e->n_lanes; ++l)
+        if (!e->join_ev[l]) LP_HIP_CHECK(hipEventCreateWithFlags(&e->join_ev[l], hipEventDisableTiming));
+    if (e->op_event.size() != e->ops.size()) e->op_event.assign(e->ops.size(), nullptr);
+    for (size_t i = 0; i < e->ops.size(); ++i)
+        if (e->ops[i].signal && !e->op_event[i]) LP_HIP_CHECK(hipEventCreateWithFlags(&e->op_event[i], hipEventDisableTiming));
+    return LP_OK;
+}
+
 extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
     int rc = check_ready(e, x, x_dtype);
     if (rc) return rc;
+    hipStream_t main_st = (hipStream_t)stream;
+    if (e->n_lanes <= 1) {
+        for (size_t i = 0; i < e->ops.size(); ++i) {
+            rc = run_op(e, i, x, x_dtype, pred, main_st);
+            if (rc) return rc;
+        }
+        return LP_OK;
+    }
+    // Independent branches of the graph (BiFusion inputs, the per-level head towers) run on side streams so that
+    // small latency-bound layers overlap; the caller's stream forks them at the start and joins them at the end, so
+    // from the outside the whole forward is still ordered on `stream`.
+    rc = ensure_lanes(e);
+    if (rc) return rc;
+    e->lane_stream[0] = main_st;
+    LP_HIP_CHECK(hipEventRecord(e->fork_ev, main_st));
+    for (int l = 1; l < e->n_lanes; ++l) LP_HIP_CHECK(hipStreamWaitEvent(e->lane_stream[l], e->fork_ev, 0));
     for (size_t i = 0; i < e->ops.size(); ++i) {
-        rc = run_op(e, i, x, x_dtype, pred, (hipStream_t)stream);
+        const Op& op = e->ops[i];
+        hipStream_t st = e->lane_stream[op.lane];
+        for (int d : op.deps) LP_HIP_CHECK(hipStreamWaitEvent(st, e->op_event[d], 0));
+        rc = run_op(e, i, x, x_dtype, pred, st);
+        if (rc) return rc;
+        if (op.signal) LP_HIP_CHECK(hipEventRecord(e->op_event[i], st));
+    }
+    for (int l = 1; l < e->n_lanes; ++l) {
+        LP_HIP_CHECK(hipEventRecord(e->join_ev[l], e->lane_stream[l]));
+        LP_HIP_CHECK(hipStreamWaitEvent(main_st, e->join_ev[l], 0));
+    }
+    return LP_OK;
+}
+
+static int forward_single_lane(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t st) {
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        int rc = run_op(e, i, x, x_dtype, pred, st);
         if (rc) return rc;
     }
     return LP_OK;
@@ -616,7 +713,7 @@ extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float
         LP_HIP_CHECK(hipEventCreate(&ev));
         e->events.push_back(ev);
     }
-    rc = lp_engine_forward(e, x, x_dtype, pred, stream);  // untimed warm run
+    rc = forward_single_lane(e, x, x_dtype, pred, (hipStream_t)stream);  // untimed warm run
     if (rc) return rc;
     for (size_t i = 0; i < n; ++i) op_ms[i] = 0.f;
     for (int r = 0; r < reps; ++r) {
@@ -644,7 +741,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     if (rc) return rc;
     if (reps < 1) reps = 3;
     hipStream_t st = (hipStream_t)stream;
-    rc = lp_engine_forward(e, x, x_dtype, pred, stream);
+    rc = forward_single_lane(e, x, x_dtype, pred, st);
     if (rc) return rc;
     hipEvent_t e0, e1;
     LP_HIP_CHECK(hipEventCreate(&e0));

@@ -29,6 +29,7 @@ SYMBOLS = {
     'lp_engine_create': (c_int, [POINTER(c_void_p), c_int]),
     'lp_engine_destroy': (None, [c_void_p]),
     'lp_engine_tensor': (c_int, [c_void_p, c_int, c_int]),
+    'lp_engine_set_lane': (c_int, [c_void_p, c_int]),
     'lp_engine_add_input': (c_int, [c_void_p, c_int]),
     'lp_engine_add_conv': (c_int, [c_void_p, POINTER(ConvDesc)]),
     'lp_engine_add_deconv2x2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -118,6 +118,10 @@ class Engine:
         self._keep.append(arr)
         return arr.ctypes.data_as(ctypes.c_void_p)
 
+    def lane(self, k):
+        """Ops added from now on run on execution lane ``k`` (0 = the caller's stream, 1 / 2 = side streams)."""
+        abi.check(self.lib.lp_engine_set_lane(self.h, int(k)), 'lp_engine_set_lane')
+
     def tensor(self, channels, sl):
         return abi.check(self.lib.lp_engine_tensor(self.h, int(channels), int(sl)), 'lp_engine_tensor')
 
@@ -185,7 +189,10 @@ class Engine:
         """BepC3 (common.py:479-501): cv3 reads [m(cv1 x), cv2 x] as two sources."""
         a = self.rep_block(m.m, [self.cba(m.cv1, srcs, sl)], sl)
         if m.concat is True:
-            return self.cba(m.cv3, [a, self.cba(m.cv2, srcs, sl)], sl)
+            self.lane(1)                                  # the shortcut branch overlaps the BottleRep stage
+            c2 = self.cba(m.cv2, srcs, sl)
+            self.lane(0)
+            return self.cba(m.cv3, [a, c2], sl)
         return self.cba(m.cv3, [a], sl)
 
     def stage(self, m, srcs, sl):
@@ -203,8 +210,10 @@ class Engine:
     def merge_layer(self, m, x, sl):
         """SimCSPSPPF / CSPSPPF (common.py:124-172) or SimSPPF / SPPF (:88-121); concats are multi-source reads."""
         if isinstance(m, L._CSPSPPFBase):
-            x1 = self.cba(m.cv4, [self.cba(m.cv3, [self.cba(m.cv1, [x], sl)], sl)], sl)
+            self.lane(1)                                  # the CSP shortcut overlaps the trunk
             y0 = self.cba(m.cv2, [x], sl)
+            self.lane(0)
+            x1 = self.cba(m.cv4, [self.cba(m.cv3, [self.cba(m.cv1, [x], sl)], sl)], sl)
             y3 = self.cba(m.cv6, [self.cba(m.cv5, [x1] + self.pools(x1, sl, m.cv4.conv.out_channels), sl)], sl)
             return self.cba(m.cv7, [y0, y3], sl)
         if isinstance(m, L._SPPFBase):
@@ -218,8 +227,11 @@ class Engine:
         up = self.tensor(t.out_channels, sl0 - 1)
         abi.check(self.lib.lp_engine_add_deconv2x2(self.h, x0, up, self._ptr(_f32(t.weight)), self._ptr(_f32(t.bias))),
                   'lp_engine_add_deconv2x2')
+        self.lane(1)                                      # the three inputs of cv3 are independent branches
         a = self.cba(m.cv1, [x1], sl0 - 1)
+        self.lane(2)
         d = self.cba(m.downsample, [self.cba(m.cv2, [x2], sl0 - 2)], sl0 - 2)
+        self.lane(0)
         return self.cba(m.cv3, [up, a, d], sl0 - 1)
 
     def _build(self, model):
@@ -247,6 +259,7 @@ class Engine:
             raise NotImplementedError('P6 heads are outside the hot-path scope')
         for i, f in enumerate(self.neck_ids):                     # effidehead.py:228-245
             sl = 3 + i
+            self.lane(i)                                  # level i: stem + class tower on lane i, box tower on the next lane
             s = self.cba(det.stems[i], [f], sl)
             c = self.cba(det.cls_convs[i], [s], sl)
             preds = [getattr(det, '%s_preds' % h)[i] for h in CLS_HEADS]
@@ -254,6 +267,7 @@ class Engine:
             bc = np.concatenate([_f32(p.bias) for p in preds], 0)
             abi.check(self.lib.lp_engine_add_head_cls(self.h, c, i, wc.shape[0], self._ptr(wc), self._ptr(bc)),
                       'lp_engine_add_head_cls')
+            self.lane((i + 1) % 3)
             r = self.cba(det.reg_convs[i], [s], sl)
             rp, cp = det.reg_preds[i], det.cor_preds[i]
             bins = det.reg_max + 1 if det.use_dfl else 1
@@ -264,6 +278,7 @@ class Engine:
             proj = self._ptr(_f32(det.proj_conv.weight).reshape(-1)) if bins > 1 else None
             abi.check(self.lib.lp_engine_add_head_box(self.h, r, i, bins, self._ptr(wb), self._ptr(bbias), proj),
                       'lp_engine_add_head_box')
+        self.lane(0)
 
     # -- execution ---------------------------------------------------------------
     def bind(self, B, H, W):
