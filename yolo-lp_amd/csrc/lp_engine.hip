@@ -40,6 +40,7 @@ struct Op {
     int cin = 0;         // logical input channels (sum over sources)
     int level = 0, reg_bins = 1;
     bool s2d = false;    // input op writes the space-to-depth form (see lp_engine_finalize)
+    int alg_kk = 0;      // algorithmic cin*k*k when it differs from the executed one (stem rewrite: 27, not 12*9)
     int lane = 0;        // execution lane (HIP stream) hint given by the host: independent branches overlap
     std::vector<int> deps;   // ops on OTHER lanes whose outputs this op reads (filled by finalize)
     bool signal = false;     // some op on another lane waits for this one
@@ -336,6 +337,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
             c.src[0] = s2d_id;
             c.stride = 1;
             c.cin = 12;
+            c.alg_kk = 27;
         }
     }
     // Cross-lane dependencies: an op waits for the latest earlier op on another lane that wrote one of the tensors it
@@ -533,7 +535,7 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
         case OP_INPUT: by = (double)e->B * e->H * e->W * 3 * esz + tbytes(op.dst); break;
         case OP_CONV: {
             const Tensor& d = e->tensors[op.dst];
-            fl = 2.0 * e->B * d.h * d.w * op.cout * op.cin * op.ksize * op.ksize;
+            fl = 2.0 * e->B * d.h * d.w * op.cout * (op.alg_kk ? op.alg_kk : op.cin * op.ksize * op.ksize);
             for (int k = 0; k < op.nsrc; ++k) by += tbytes(op.src[k]);
             by += tbytes(op.dst) + (op.res >= 0 ? tbytes(op.res) : 0) + (double)op.cout * op.cin * op.ksize * op.ksize * esz;
             break;
