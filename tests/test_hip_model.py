@@ -230,3 +230,26 @@ def test_infer_entry_point_on_gpu(tmp_path, monkeypatch):
     assert torch.equal(gpu.cpu()[:, 20:], cpu[:, 20:])               # the eight arg-max indices
     half = infer.run(device='0', save_dir=str(tmp_path / 'o3'), half=True, **kw)[0]
     assert half.shape[1] == 28
+
+
+def test_gather_detections_rccl_on_side_stream():
+    """The all-gather of padded detections through RCCL (backend nccl), issued on a side stream like bench.py does;
+    one rank is all a one-GPU box offers, so this checks the plumbing (RCCL loads, the collective runs on our tensors
+    and stream), the multi-rank data movement itself is covered by the gloo test on CPU."""
+    import torch.distributed as dist
+    from yolov6.core.sharded import gather_detections
+    from yolov6.hip.runtime import nms_padded
+    port = 29600 + os.getpid() % 1000
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda:0'))
+    try:
+        pred = synth_pred(3, 2100, 31, frac_hot=0.2).cuda()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            det, count, _ = nms_padded(pred, 0.4, 0.45, 100)
+            det_all, count_all = gather_detections(det, count, force_collective=True)
+        side.synchronize()
+        assert torch.equal(det_all, det) and torch.equal(count_all, count)
+    finally:
+        dist.destroy_process_group()

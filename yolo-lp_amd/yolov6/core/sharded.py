@@ -18,7 +18,7 @@ def shard_bounds(global_batch, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_detections(det, count, group=None, out=None):
+def gather_detections(det, count, group=None, out=None, force_collective=False):
     """All-gather padded detections of equal-sized shards.
 
     det [b, max_det, 28] fp32 and count [b] int32 of this rank -> (det_all [world*b, max_det, 28],
@@ -29,7 +29,7 @@ def gather_detections(det, count, group=None, out=None):
     if out is None:
         out = (det.new_empty((world * det.shape[0],) + tuple(det.shape[1:])), count.new_empty(world * count.shape[0]))
     det_all, count_all = out
-    if world == 1:
+    if world == 1 and not force_collective:
         det_all.copy_(det)
         count_all.copy_(count)
         return det_all, count_all
