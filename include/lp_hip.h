@@ -154,6 +154,21 @@ size_t lp_nms_workspace_bytes(int B, int N);
 int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det, int32_t* count,
            int32_t* keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Callers either side of the path.
+ *
+ * lp_preprocess_letterbox: Inferer.precess_image (yolov6/core/inferer.py:191-201) with letterbox
+ * (yolov6/data/data_augment.py:30-61) for one frame.  img: device uint8 [h0,w0,3] BGR (cv2.imread layout);
+ * out: device [3,H,W] of out_dtype, RGB, /255.  The frame is resized (bilinear, OpenCV INTER_LINEAR fixed-point
+ * scheme) to rh x rw, placed at (top,left) and surrounded by 114.  rh == h0 && rw == w0 means no resize.
+ *
+ * lp_rescale_round: Inferer.rescale (inferer.py:203-228) + .round() (:100) on columns 0..11 of n detection rows
+ * (row stride 28 floats), in place: v = round_half_even(clamp((v - pad) / ratio, 0, img_w | img_h)).
+ * ------------------------------------------------------------------------------------------------- */
+int lp_preprocess_letterbox(const unsigned char* img, int h0, int w0, void* out, int out_dtype, int H, int W, int rh, int rw,
+                            int top, int left, void* stream);
+int lp_rescale_round(float* det, int n, double ratio, double padx, double pady, int img_w, int img_h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

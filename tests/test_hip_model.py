@@ -253,3 +253,31 @@ def test_gather_detections_rccl_on_side_stream():
         assert torch.equal(det_all, det) and torch.equal(count_all, count)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('h0,w0,size', [(1160, 720, [640, 640]), (480, 640, [640, 640]), (640, 640, [640, 640]),
+                                         (300, 500, [320, 416]), (2000, 1500, [640, 640])])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_preprocess_letterbox_matches_host_mirror(h0, w0, size, dtype):
+    """lp_preprocess_letterbox == the host mirror's letterbox + transpose + /255 (bit-exact: same integer bilinear)."""
+    from yolov6.hip.runtime import preprocess_letterbox
+    from yolov6.core.inferer import Inferer
+    rng = np.random.default_rng(h0 + w0)
+    frame = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+    ref, _ = Inferer.precess_image(frame, size, 32, dtype == torch.float16)
+    got = preprocess_letterbox(torch.from_numpy(frame).cuda(), size, 32, dtype)
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_rescale_round_matches_reference_formula():
+    from yolov6.hip.runtime import rescale_round
+    from yolov6.core.inferer import Inferer
+    g = torch.Generator().manual_seed(5)
+    det = torch.rand(300, 28, generator=g) * 700 - 30
+    det[:7, :12] = torch.tensor([0.5, 1.5, 2.5, -0.5, 639.5, 415.5, 100.25, 100.75, 3.5, 4.5, 1e-3, 720.0])   # ties, edges
+    for ori, tgt in (((640, 416), (1160, 720, 3)), ((640, 640), (480, 640, 3)), ((320, 416), (300, 500, 3))):
+        ref = det.clone()
+        ref[:, :12] = Inferer.rescale(ori, ref[:, :12], tgt).round()
+        got = rescale_round(ori, det.clone().cuda(), tgt).cpu()
+        assert torch.equal(got, ref)

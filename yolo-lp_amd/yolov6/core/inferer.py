@@ -66,8 +66,14 @@ class Inferer:
         fps = CalcFPS()
         results = []
         for img_src, img_path, _ in self.files:
-            img, img_src = self.precess_image(img_src, self.img_size, self.stride, self.half)
-            img = img.to(self.device)
+            if self.device.type != 'cpu':      # letterbox + BGR->RGB + /255 in one HIP kernel on the uploaded frame
+                from yolov6.hip import runtime
+                frame = torch.from_numpy(np.ascontiguousarray(img_src)).to(self.device)
+                img = runtime.preprocess_letterbox(frame, self.img_size, self.stride,
+                                                   torch.float16 if self.half else torch.float32)
+            else:
+                img, img_src = self.precess_image(img_src, self.img_size, self.stride, self.half)
+                img = img.to(self.device)
             if len(img.shape) == 3:
                 img = img[None]
             t1 = time.time()
@@ -84,7 +90,11 @@ class Inferer:
             gn = torch.tensor(img_src.shape)[[1, 0, 1, 0]]
             gn_cor = torch.tensor(img_src.shape)[[1, 0, 1, 0, 1, 0, 1, 0]]
             if len(det):
-                det[:, :12] = self.rescale(img.shape[2:], det[:, :12], img_src.shape).round()
+                if det.is_cuda:
+                    from yolov6.hip import runtime
+                    runtime.rescale_round(img.shape[2:], det, img_src.shape)
+                else:
+                    det[:, :12] = self.rescale(img.shape[2:], det[:, :12], img_src.shape).round()
                 rows = det.detach().float().cpu()
                 if save_txt:
                     with open(txt_path + '.txt', 'a') as f:

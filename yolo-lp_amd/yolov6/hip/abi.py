@@ -5,7 +5,7 @@ this module raises -- nothing falls back to eager torch ops on a GPU.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p  # noqa: F401
 
 LP_F16, LP_BF16, LP_F32 = 0, 1, 2
 LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
@@ -52,6 +52,9 @@ SYMBOLS = {
     'lp_engine_autotune': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'lp_engine_op_variant': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     'lp_nms_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'lp_preprocess_letterbox': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
+    'lp_rescale_round': (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_size_t, c_void_p]),
 }

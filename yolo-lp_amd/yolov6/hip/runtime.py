@@ -425,3 +425,38 @@ def non_max_suppression(prediction, conf_thres, iou_thres, max_det):
         src.copy_(work)          # keep the reference's in-place obj*cls side effect on the caller's tensor
     counts = count.cpu().tolist()
     return [det[b, :n] for b, n in enumerate(counts)]
+
+
+# ---------------------------------------------------------------------------------------------------
+def preprocess_letterbox(frame_bgr_u8, img_size, stride, dtype):
+    """GPU form of Inferer.precess_image: device uint8 [h,w,3] BGR frame -> [3,H,W] RGB /255 tensor of ``dtype``.
+    Geometry (ratio, resized size, padding) is the reference's letterbox arithmetic, done on the host."""
+    from yolov6.data.data_augment import letterbox_geometry
+    if not (frame_bgr_u8.is_cuda and frame_bgr_u8.dtype == torch.uint8 and frame_bgr_u8.dim() == 3 and
+            frame_bgr_u8.shape[2] == 3 and frame_bgr_u8.is_contiguous()):
+        raise ValueError('frame must be a contiguous uint8 CUDA tensor [h, w, 3]')
+    h0, w0 = frame_bgr_u8.shape[:2]
+    _, (rw, rh), (top, bottom, left, right), _ = letterbox_geometry((h0, w0), img_size, stride=stride)
+    H, W = rh + top + bottom, rw + left + right
+    out = torch.empty(3, H, W, dtype=dtype, device=frame_bgr_u8.device)
+    with torch.cuda.device(out.device):
+        abi.check(abi.load().lp_preprocess_letterbox(ctypes.c_void_p(frame_bgr_u8.data_ptr()), h0, w0,
+                                                     ctypes.c_void_p(out.data_ptr()), _DT[dtype], H, W, rh, rw, top, left,
+                                                     ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)),
+                  'lp_preprocess_letterbox')
+    return out
+
+
+def rescale_round(ori_shape, det, target_shape):
+    """GPU form of ``Inferer.rescale(ori_shape, det[:, :12], target_shape).round()``, in place on det [n, 28]."""
+    if not (det.is_cuda and det.dtype == torch.float32 and det.dim() == 2 and det.shape[1] == abi.LP_DET_COLS and
+            det.stride(1) == 1 and det.stride(0) == abi.LP_DET_COLS):
+        raise ValueError('det must be a CUDA fp32 [n, 28] tensor with contiguous rows')
+    ratio = min(ori_shape[0] / target_shape[0], ori_shape[1] / target_shape[1])
+    padx, pady = (ori_shape[1] - target_shape[1] * ratio) / 2, (ori_shape[0] - target_shape[0] * ratio) / 2
+    with torch.cuda.device(det.device):
+        abi.check(abi.load().lp_rescale_round(ctypes.c_void_p(det.data_ptr()), det.shape[0], float(ratio), float(padx),
+                                              float(pady), int(target_shape[1]), int(target_shape[0]),
+                                              ctypes.c_void_p(torch.cuda.current_stream(det.device).cuda_stream)),
+                  'lp_rescale_round')
+    return det
