@@ -122,6 +122,10 @@ int lp_engine_num_anchors(const lp_engine* e);
  * three neck maps) stays in the arena (lp_engine_tensor_info). */
 int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream);
 
+/* enable != 0: lp_engine_forward captures its launches into a hipGraph on first use with a given (x, pred, dtype,
+ * launch geometry) and replays it afterwards; any other pointers re-capture.  For launch-bound shapes (batch 1). */
+int lp_engine_set_graph(lp_engine* e, int enable);
+
 /* Introspection for benchmarks: ops of the frozen graph and per-op device time (hipEvent pairs on
  * `stream`, one untimed warm run first).  op_ms has lp_engine_num_ops() entries (milliseconds). */
 int lp_engine_num_ops(const lp_engine* e);

@@ -281,3 +281,25 @@ def test_rescale_round_matches_reference_formula():
         ref[:, :12] = Inferer.rescale(ori, ref[:, :12], tgt).round()
         got = rescale_round(ori, det.clone().cuda(), tgt).cpu()
         assert torch.equal(got, ref)
+
+
+def test_graph_replay_matches_eager_launches():
+    """hipGraph replay of the forward (lp_engine_set_graph) == re-issued launches, also after the input pointer or the
+    shape changed (re-capture), and the persistent prediction buffer is overwritten by the next call."""
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=0.0625, sigma=1.5).cuda().half()
+    xs = [torch.rand(1, 3, 128, 96, generator=torch.Generator().manual_seed(k)).cuda().half() for k in range(3)]
+    xs.append(torch.rand(2, 3, 64, 160, generator=torch.Generator().manual_seed(9)).cuda().half())
+    with torch.no_grad():
+        ref = [m(x)[0].clone() for x in xs]
+        m.lp_graph = True
+        for _ in range(2):
+            for x, r in zip(xs, ref):
+                p, feats = m(x)
+                assert torch.equal(p, r)
+        p1, _ = m(xs[0])
+        keep = p1.clone()
+        p2, _ = m(xs[1])
+        assert p2.data_ptr() == p1.data_ptr() and torch.equal(p2, ref[1]) and not torch.equal(keep, ref[1])
+        m.lp_graph = False
+        assert torch.equal(m(xs[2])[0], ref[2])

@@ -84,6 +84,13 @@ struct lp_engine {
     hipStream_t lane_stream[LP_MAX_LANES] = {nullptr, nullptr, nullptr};   // [0] = the caller's stream
     std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {nullptr, nullptr, nullptr};
+    bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
+    const void* graph_x = nullptr;    // the capture is valid for exactly these pointers / dtype / tuning state
+    float* graph_pred = nullptr;
+    int graph_x_dtype = -1;
+    unsigned long long graph_epoch = 0, epoch = 1;   // epoch changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
     std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile}
 };
@@ -110,6 +117,8 @@ extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
 extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (hipEvent_t ev : e->op_event) if (ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     for (int l = 1; l < LP_MAX_LANES; ++l) { if (e->join_ev[l]) (void)hipEventDestroy(e->join_ev[l]); if (e->lane_stream[l]) (void)hipStreamDestroy(e->lane_stream[l]); }
@@ -560,6 +569,7 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
 // ---- execution ------------------------------------------------------------------------------------------
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
+    ++e->epoch;
     const Op& op = e->ops[idx];
     Launch& L = e->launches[idx];
     L.is_conv = !(op.kind == OP_INPUT || op.kind == OP_POOL);
@@ -662,10 +672,8 @@ static int ensure_lanes(lp_engine* e) {
     return LP_OK;
 }
 
-extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
-    int rc = check_ready(e, x, x_dtype);
-    if (rc) return rc;
-    hipStream_t main_st = (hipStream_t)stream;
+static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t main_st) {
+    int rc;
     if (e->n_lanes <= 1) {
         for (size_t i = 0; i < e->ops.size(); ++i) {
             rc = run_op(e, i, x, x_dtype, pred, main_st);
@@ -693,6 +701,45 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
         LP_HIP_CHECK(hipEventRecord(e->join_ev[l], e->lane_stream[l]));
         LP_HIP_CHECK(hipStreamWaitEvent(main_st, e->join_ev[l], 0));
     }
+    return LP_OK;
+}
+
+extern "C" int lp_engine_set_graph(lp_engine* e, int enable) {
+    if (!e) return fail(LP_ERR_ARG, "lp_engine_set_graph: null engine");
+    e->use_graph = enable != 0;
+    return LP_OK;
+}
+
+extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    hipStream_t main_st = (hipStream_t)stream;
+    if (!e->use_graph) return issue_forward(e, x, x_dtype, pred, main_st);
+    // hipGraph path: the ~80 launches (and the lane fork/join events) of one forward are captured once per
+    // (input pointer, output pointer, dtype, launch geometry) and replayed with a single hipGraphLaunch -- what the
+    // per-image loop of Inferer needs, where the forward is launch-bound.
+    const bool valid = e->graph_exec && e->graph_x == x && e->graph_pred == pred && e->graph_x_dtype == x_dtype &&
+                       e->graph_epoch == e->epoch;
+    if (!valid) {
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        rc = ensure_lanes(e);
+        if (rc) return rc;
+        hipGraph_t g = nullptr;
+        if (!e->cap_stream) LP_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        LP_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        rc = issue_forward(e, x, x_dtype, pred, e->cap_stream);
+        hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (ce != hipSuccess) return fail(LP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        ce = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ce != hipSuccess) { e->graph_exec = nullptr; return fail(LP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); }
+        e->graph_x = x;
+        e->graph_pred = pred;
+        e->graph_x_dtype = x_dtype;
+        e->graph_epoch = e->epoch;
+    }
+    LP_HIP_CHECK(hipGraphLaunch(e->graph_exec, main_st));
     return LP_OK;
 }
 

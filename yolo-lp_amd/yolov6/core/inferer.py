@@ -48,6 +48,7 @@ class Inferer:
             self.model.model.float()
             self.half = False
         if self.device.type != 'cpu':   # warm-up: builds the engine and tunes it for this shape
+            self.model.model.lp_graph = True      # per-image loop = launch-bound: replay the forward as one hipGraph
             self.model(torch.zeros(1, 3, *self.img_size).to(self.device).type_as(next(self.model.model.parameters())))
         self.files = LoadData(source)
         self.source = source

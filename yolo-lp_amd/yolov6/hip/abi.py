@@ -45,6 +45,7 @@ SYMBOLS = {
                                       POINTER(c_int), POINTER(c_int)]),
     'lp_engine_num_anchors': (c_int, [c_void_p]),
     'lp_engine_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'lp_engine_set_graph': (c_int, [c_void_p, c_int]),
     'lp_engine_num_ops': (c_int, [c_void_p]),
     'lp_engine_op_info': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_double), POINTER(c_double)]),

@@ -76,6 +76,8 @@ class Engine:
         self.neck_ids = []
         self.tuned = set()         # (B, H, W) shapes whose per-layer kernel variants were autotuned
         self.autotune = os.environ.get('LP_AUTOTUNE', '1') != '0'
+        self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
+        self._graph_pred = None
         self.input_id = self.tensor(3, 0)
         abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
 
@@ -296,6 +298,12 @@ class Engine:
         self.bound = (B, H, W)
         self.n_anchors = self.lib.lp_engine_num_anchors(self.h)
 
+    def set_graph(self, enable=True):
+        """Replay the forward as one hipGraph (launch-bound shapes, e.g. the per-image loop of Inferer).  The prediction
+        tensor returned by ``forward`` is then a persistent buffer that the next forward overwrites."""
+        self.graph = bool(enable)
+        abi.check(self.lib.lp_engine_set_graph(self.h, 1 if enable else 0), 'lp_engine_set_graph')
+
     def tensor_view(self, tid):
         """Zero-copy [B,C,h,w] view (channels_last strides) of an arena tensor."""
         off, c, cs, h, w = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -317,7 +325,12 @@ class Engine:
         B, _, H, W = x.shape
         with torch.cuda.device(self.device):
             self.bind(B, H, W)
-            pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
+            if self.graph:      # fixed output address so that the captured graph stays valid
+                if self._graph_pred is None or self._graph_pred.shape != (B, self.n_anchors, abi.LP_PRED_COLS):
+                    self._graph_pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
+                pred = self._graph_pred
+            else:
+                pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
             if self.autotune and self.bound not in self.tuned:
                 # first batch of this shape: time the kernel variants of every conv layer in place, keep the best
                 abi.check(self.lib.lp_engine_autotune(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
@@ -375,9 +388,12 @@ def engine_for(model, dtype=None):
 
 
 def model_forward(model, x):
+    # model.lp_graph = True (set by Inferer) switches the engine to hipGraph replay
     """``Model.forward`` on a GPU: [pred[B,N,290] fp32, [f_s8, f_s16, f_s32]].  The feature maps are
     zero-copy channels_last views of the engine's arena (valid until the next forward of this model)."""
     eng = engine_for(model)
+    if bool(getattr(model, 'lp_graph', False)) != eng.graph:
+        eng.set_graph(getattr(model, 'lp_graph', False))
     pred = eng.forward(x)
     return [pred, [eng.tensor_view(t) for t in eng.neck_ids]]
 
