@@ -815,7 +815,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
                     last_tw = e->launches[i].a.TW;
                     if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;   // warm
                     float ms_min = -1.f;
-                    for (int round = 0; round < 2; ++round) {     // best of two rounds of `reps` launches
+                    for (int round = 0; round < 3; ++round) {     // best of three rounds of `reps` launches
                         LP_HIP_CHECK(hipEventRecord(e0, st));
                         for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
                         LP_HIP_CHECK(hipEventRecord(e1, st));

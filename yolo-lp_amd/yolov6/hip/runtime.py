@@ -334,7 +334,7 @@ class Engine:
             if self.autotune and self.bound not in self.tuned:
                 # first batch of this shape: time the kernel variants of every conv layer in place, keep the best
                 abi.check(self.lib.lp_engine_autotune(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
-                                                      ctypes.c_void_p(pred.data_ptr()), self._stream(), 3),
+                                                      ctypes.c_void_p(pred.data_ptr()), self._stream(), 5),
                           'lp_engine_autotune')
                 self.tuned.add(self.bound)
             abi.check(self.lib.lp_engine_forward(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
