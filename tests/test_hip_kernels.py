@@ -88,6 +88,86 @@ def test_conv(case, dtype):
     assert torch.isfinite(got).all()
 
 
+STREAM_CASES = [
+    # (cin list, cout, act, residual, h, w, B)
+    ([64], 64, 'relu', False, 40, 40, 2),                 # one K-chunk, exact tiles
+    ([256], 128, 'relu', False, 20, 20, 2),               # 128-row weight packing, four chunks
+    ([64, 64, 64, 64], 64, 'relu', False, 12, 20, 2),     # SPPF cv5: four sources
+    ([128, 64, 64], 64, 'silu', False, 16, 16, 1),        # BiFusion concat
+    ([96], 192, 'relu', True, 13, 7, 3),                  # chunk tail (96 of 128 B), residual, ragged pixel count
+    ([128], 128, 'none', False, 9, 5, 1),                 # fewer pixels than one workgroup's tiles
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('variant', [(5, 2), (5, 3), (6, 2), (6, 3)], ids=lambda v: 'wc%d-rd%d' % (2 if v[0] == 5 else 4, v[1]))
+@pytest.mark.parametrize('case', STREAM_CASES, ids=lambda c: '%s-%d-%s%s' % ('+'.join(map(str, c[0])), c[1], c[2], '-res' if c[3] else ''))
+def test_conv1x1_stream(case, variant, dtype):
+    """The streaming 1x1 kernel against the oracle, and bit-for-bit against the implicit-GEMM kernel on the same packing."""
+    from yolov6.hip import abi
+    cins, cout, act, use_res, h, w, B = case
+    sl = 5
+    eng = _engine(dtype)
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, 1, 1), 1, (2.0 / cin) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    res_id = eng.tensor(cout, sl) if use_res else None
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, bias, 1, 1, act_id, sl, res=res_id, alpha=0.75)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    eng.autotune = False
+    xs = [_rand((B, c, h, w), 10 + i) for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()
+    for t, x in zip(srcs, xs):
+        _fill(eng, t, x)
+    res = _rand((B, cout, h, w), 20) if use_res else None
+    if use_res:
+        _fill(eng, res_id, res)
+    conv_op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)                                     # default implicit-GEMM variant
+    base = eng.tensor_view(dst).clone()
+    eng.tensor_view(dst).zero_()
+    # the kernel takes an op only if its weight packing has whole cout tiles of the wave (the engine packs by least
+    # padding: 128-row tiles only for multiples of 128) and the resident weights + staging fit the 160 KiB of LDS
+    sz = torch.empty(0, dtype=dtype).element_size()
+    wc = 2 if variant[0] == 5 else 4
+    nchunks = sum(-(-((c + 7) // 8 * 8) // (128 // sz)) for c in cins)
+    fits = (wc == 2 or cout % 128 == 0) and nchunks * 32 * wc * 128 + 4 * (128 // wc) * (32 * wc * sz + 16) <= 160 * 1024
+    if not fits:
+        with pytest.raises(RuntimeError):
+            eng.set_variant(conv_op, *variant)
+        return
+    eng.set_variant(conv_op, *variant)
+    _run(eng, B, H, W)
+    got = eng.tensor_view(dst)
+    assert torch.equal(got, base)
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(wt), bias)
+    ref = {'none': lambda t: t, 'relu': F.relu, 'silu': F.silu}[act](ref)
+    if use_res:
+        ref = q(ref) + 0.75 * q(res) if dtype != torch.float32 else ref + 0.75 * res
+    assert rel_err(got.float().cpu(), ref) <= TOL[dtype]
+
+
+def test_conv1x1_stream_rejects_unfit_ops():
+    from yolov6.hip import abi
+    eng = _engine(torch.float16)
+    src = eng.tensor(16, 5)
+    eng.conv([src], _rand((8, 16, 1, 1), 1), _rand((8,), 2), 1, 1, abi.LP_ACT_RELU, 5)       # 32-row packing
+    src3 = eng.tensor(64, 5)
+    eng.conv([src3], _rand((64, 64, 3, 3), 1), _rand((64,), 2), 3, 1, abi.LP_ACT_RELU, 5)   # 3x3
+    eng.finish()
+    eng.bind(1, 64, 64)
+    n = eng.lib.lp_engine_num_ops(eng.h)
+    for op in (n - 2, n - 1):
+        with pytest.raises(RuntimeError):
+            eng.set_variant(op, 5, 2)
+    with pytest.raises(RuntimeError):
+        eng.set_variant(0, 0, 1)                          # the input op has no variants
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('cin,cout,h,w', [(128, 128, 20, 20), (64, 64, 10, 14), (16, 24, 6, 6)])
 def test_deconv2x2(cin, cout, h, w, dtype):

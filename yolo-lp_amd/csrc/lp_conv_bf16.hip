@@ -1,8 +1,12 @@
 // Instantiates the implicit-GEMM conv kernels (lp_conv_kernel.inc) for bf16 activations.
 #include "lp_conv_kernel.inc"
+#include "lp_conv1x1_stream.inc"
 
 namespace lp {
 int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
     return launch_dtype<bf16>(cfg, mode, ksize, stride, nbuf, a, st);
+}
+int conv_stream_launch_bf16(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
+    return stream_launch_dtype<bf16>(wc, rd, a, cb_pack, lds, st);
 }
 }  // namespace lp

@@ -1,8 +1,12 @@
 // Instantiates the implicit-GEMM conv kernels (lp_conv_kernel.inc) for f16 activations.
 #include "lp_conv_kernel.inc"
+#include "lp_conv1x1_stream.inc"
 
 namespace lp {
 int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
     return launch_dtype<f16>(cfg, mode, ksize, stride, nbuf, a, st);
+}
+int conv_stream_launch_f16(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
+    return stream_launch_dtype<f16>(wc, rd, a, cb_pack, lds, st);
 }
 }  // namespace lp

@@ -47,6 +47,7 @@ struct Op {
     std::vector<float> weight, bias, proj;  // host fp32, reference layouts
     // filled by finalize
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
+    int stream_wc = 0, stream_rd = 2;   // stream_wc != 0: the streaming 1x1 kernel (2 or 4 cout tiles per wave) runs this op
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -56,6 +57,7 @@ struct Launch {
     ConvArgs a;
     long long pred_off = 0;
     int cfg = 0, mode = 0, ks = 1, st = 1, nbuf = 1;
+    int stream_wc = 0, stream_rd = 2, cb_pack = 0;
     bool is_conv = false;
 };
 
@@ -92,7 +94,7 @@ struct lp_engine {
     int graph_x_dtype = -1;
     unsigned long long graph_epoch = 0, epoch = 1;   // epoch changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile}
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd}
 };
 
 #define LP_MAX_LANES 3
@@ -508,7 +510,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -629,6 +631,9 @@ static int prepare_op(lp_engine* e, size_t idx) {
     L.ks = ks;
     L.st = stv;
     L.nbuf = op.nbuf;
+    L.stream_wc = op.stream_wc;
+    L.stream_rd = op.stream_rd;
+    L.cb_pack = s.CB;
     return LP_OK;
 }
 
@@ -644,6 +649,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
+    if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.stream_rd, L.a, L.cb_pack, st);
     if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
     if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
     ConvArgs a = L.a;
@@ -799,8 +805,23 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         Op& op = e->ops[i];
         if (!e->launches[i].is_conv || op.mode != MODE_ACT) continue;
         const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
-        int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile;
+        int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile, best_wc = 0, best_rd = 2;
         float best_ms = -1.f;
+        int trc = LP_OK;
+        auto time_current = [&]() -> float {   // best of three rounds of `reps` launches of the op as prepared; < 0: failed
+            if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) return -1.f;   // warm
+            float ms_min = -1.f;
+            for (int round = 0; round < 3; ++round) {
+                if (hipEventRecord(e0, st) != hipSuccess) { trc = LP_ERR_HIP; return -1.f; }
+                for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
+                float ms = 0.f;
+                if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { trc = LP_ERR_HIP; return -1.f; }
+                if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+            }
+            return ms_min;
+        };
+        op.stream_wc = 0;
         for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
             if (conv_shape(e->dtype, cfg, 1, 1).CB != cb) continue;
             for (int nb = 1; nb <= (cfg == CFG_C ? 1 : 2); ++nb) {
@@ -813,38 +834,70 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
                     if (e->launches[i].a.TH == last_th && e->launches[i].a.TW == last_tw) break;   // no further candidates
                     last_th = e->launches[i].a.TH;
                     last_tw = e->launches[i].a.TW;
-                    if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;   // warm
-                    float ms_min = -1.f;
-                    for (int round = 0; round < 3; ++round) {     // best of three rounds of `reps` launches
-                        LP_HIP_CHECK(hipEventRecord(e0, st));
-                        for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
-                        LP_HIP_CHECK(hipEventRecord(e1, st));
-                        LP_HIP_CHECK(hipEventSynchronize(e1));
-                        float ms = 0.f;
-                        LP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                        if (ms_min < 0.f || ms < ms_min) ms_min = ms;
-                    }
-                    if (best_ms < 0.f || ms_min < best_ms) { best_ms = ms_min; best_cfg = cfg; best_nb = nb; best_tile = tile; }
+                    const float ms = time_current();
+                    if (ms >= 0.f && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best_cfg = cfg; best_nb = nb; best_tile = tile; }
                 }
             }
         }
+        // 1x1 stride-1 layers: the streaming kernel reads the same packing
+        if (op.kind == OP_CONV && op.ksize == 1 && op.stride == 1 && !getenv("LP_NO_STREAM")) {
+            op.cfg = best_cfg; op.nbuf = best_nb; op.tile = best_tile;
+            for (int wc = 2; wc <= 4; wc += 2) {
+                if (conv_stream_lds(e->dtype, wc, op.nchunks, cb) < 0) continue;
+                for (int rd = 2; rd <= 3; ++rd) {
+                    op.stream_wc = wc;
+                    op.stream_rd = rd;
+                    if (prepare_op(e, i) != LP_OK) continue;
+                    const float ms = time_current();
+                    if (ms >= 0.f && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best_wc = wc; best_rd = rd; }
+                }
+            }
+        }
+        if (trc) return fail(trc, "autotune: event timing failed");
         op.cfg = best_cfg;
         op.nbuf = best_nb;
         op.tile = best_tile;
+        op.stream_wc = best_wc;
+        op.stream_rd = best_rd;
         rc = prepare_op(e, i);
         if (rc) return rc;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd});
     e->tuned[{e->B, e->H, e->W}] = choice;
+    return LP_OK;
+}
+
+extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int nbuf) {
+    if (!e || !e->finalized || op_idx < 0 || op_idx >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_set_op_variant: op index");
+    Op& op = e->ops[op_idx];
+    if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
+    const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
+    const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
+    if (cfg == 5 || cfg == 6) {
+        const int wc = cfg == 5 ? 2 : 4;
+        if (op.kind != OP_CONV || ks != 1 || stv != 1 || conv_stream_lds(e->dtype, wc, op.nchunks, cb) < 0 || (nbuf != 2 && nbuf != 3))
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the streaming 1x1 kernel does not fit this op");
+        op.stream_wc = wc;
+        op.stream_rd = nbuf;
+    } else {
+        if (cfg < 0 || cfg >= CFG_COUNT || conv_shape(e->dtype, cfg, ks, stv).CB != cb || nbuf < 1 || nbuf > (cfg == CFG_C ? 1 : 2))
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: variant does not share the op's weight packing");
+        op.stream_wc = 0;
+        op.cfg = cfg;
+        op.nbuf = nbuf;
+    }
+    e->tuned.erase({e->B, e->H, e->W});
+    if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
     return LP_OK;
 }
 
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
-    if (cfg) *cfg = e->ops[op].cfg;
-    if (nbuf) *nbuf = e->ops[op].nbuf;
+    const bool stream = e->ops[op].stream_wc != 0;   // reported as cfg 5 / 6 (2 / 4 cout tiles per wave), nbuf = ring depth
+    if (cfg) *cfg = stream ? (e->ops[op].stream_wc == 2 ? 5 : 6) : e->ops[op].cfg;
+    if (nbuf) *nbuf = stream ? e->ops[op].stream_rd : e->ops[op].nbuf;
     return LP_OK;
 }

@@ -52,6 +52,7 @@ SYMBOLS = {
     'lp_engine_profile': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int]),
     'lp_engine_autotune': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'lp_engine_op_variant': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
+    'lp_engine_set_op_variant': (c_int, [c_void_p, c_int, c_int, c_int]),
     'lp_nms_workspace_bytes': (c_size_t, [c_int, c_int]),
     'lp_preprocess_letterbox': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),

@@ -304,6 +304,11 @@ class Engine:
         self.graph = bool(enable)
         abi.check(self.lib.lp_engine_set_graph(self.h, 1 if enable else 0), 'lp_engine_set_graph')
 
+    def set_variant(self, op, cfg, nbuf):
+        """Force the kernel variant of conv op ``op`` (see lp_engine_set_op_variant); switches the autotuner off."""
+        self.autotune = False
+        abi.check(self.lib.lp_engine_set_op_variant(self.h, op, cfg, nbuf), 'lp_engine_set_op_variant')
+
     def tensor_view(self, tid):
         """Zero-copy [B,C,h,w] view (channels_last strides) of an arena tensor."""
         off, c, cs, h, w = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -363,7 +368,7 @@ class Engine:
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
-                            variant='%s%d' % ('ABCDE'[cfg.value], nb.value)))
+                            variant='%s%d' % ('ABCDESW'[cfg.value], nb.value)))
         return ops
 
 
