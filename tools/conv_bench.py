@@ -22,6 +22,7 @@ ap.add_argument('--hw', type=int, default=40, help='feature-map height = width a
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
 ap.add_argument('--dtype', default='f16')
+ap.add_argument('--variant', default='', help='force a kernel variant: cfg,nbuf (cfg 0..4 = tiles A..E, 5/6 = streaming 1x1)')
 ap.add_argument('--stamps', action='store_true', help='needs LP_HIP_LIB=yolo-lp_amd/libyololp_hip_stamps.so (make stamps)')
 args = ap.parse_args()
 
@@ -41,12 +42,14 @@ if args.stamps:
     stamps = torch.zeros(1 << 20, dtype=torch.int64, device='cuda:0')
     eng.lib.lpdbg_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 eng.bind(args.batch, H, W)
+if args.variant:
+    eng.set_variant(1, *[int(v) for v in args.variant.split(',')])
 eng.tensor_view(src).copy_(torch.randn(args.batch, args.cin, args.hw, args.hw, generator=g).to('cuda:0', dt))
 ops = eng.profile(torch.zeros(args.batch, 3, H, W, device='cuda:0', dtype=dt), reps=args.iters)
 o = ops[1]
-print('%s k%d s%d %d->%d @%dx%d B%d variant %s: %.1f us  %.1f TFLOP/s' % (
+print('%s k%d s%d %d->%d @%dx%d B%d variant %s: %.1f us  %.1f TFLOP/s  %.2f TB/s (algorithmic)' % (
     args.dtype, args.k, args.s, args.cin, args.cout, args.hw, args.hw, args.batch, o['variant'], o['ms'] * 1e3,
-    o['flops'] / o['ms'] / 1e9))
+    o['flops'] / o['ms'] / 1e9, o['bytes'] / o['ms'] / 1e9))
 
 if stamps is not None:
     st = stamps.view(-1, 8).cpu()
