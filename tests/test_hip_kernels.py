@@ -94,13 +94,14 @@ STREAM_CASES = [
     ([256], 128, 'relu', False, 20, 20, 2),               # 128-row weight packing, four chunks
     ([64, 64, 64, 64], 64, 'relu', False, 12, 20, 2),     # SPPF cv5: four sources
     ([128, 64, 64], 64, 'silu', False, 16, 16, 1),        # BiFusion concat
-    ([96], 192, 'relu', True, 13, 7, 3),                  # chunk tail (96 of 128 B), residual, ragged pixel count
+    ([96], 192, 'relu', True, 13, 7, 3),                  # 96 channels: whole chunks only in fp32; residual, ragged pixel count
+    ([64], 128, 'relu', True, 13, 7, 3),                  # residual with 128 couts per wave
     ([128], 128, 'none', False, 9, 5, 1),                 # fewer pixels than one workgroup's tiles
 ]
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('variant', [(5, 2), (5, 3), (6, 2), (6, 3)], ids=lambda v: 'wc%d-rd%d' % (2 if v[0] == 5 else 4, v[1]))
+@pytest.mark.parametrize('variant', [(5, 2), (6, 2)], ids=lambda v: 'wc%d' % (2 if v[0] == 5 else 4))
 @pytest.mark.parametrize('case', STREAM_CASES, ids=lambda c: '%s-%d-%s%s' % ('+'.join(map(str, c[0])), c[1], c[2], '-res' if c[3] else ''))
 def test_conv1x1_stream(case, variant, dtype):
     """The streaming 1x1 kernel against the oracle, and bit-for-bit against the implicit-GEMM kernel on the same packing."""
@@ -131,11 +132,15 @@ def test_conv1x1_stream(case, variant, dtype):
     base = eng.tensor_view(dst).clone()
     eng.tensor_view(dst).zero_()
     # the kernel takes an op only if its weight packing has whole cout tiles of the wave (the engine packs by least
-    # padding: 128-row tiles only for multiples of 128) and the resident weights + staging fit the 160 KiB of LDS
+    # padding: 128-row tiles only for multiples of 128), every source is made of whole 128-byte K-chunks, and the
+    # resident weights + bias + staging fit the 160 KiB of LDS
     sz = torch.empty(0, dtype=dtype).element_size()
     wc = 2 if variant[0] == 5 else 4
-    nchunks = sum(-(-((c + 7) // 8 * 8) // (128 // sz)) for c in cins)
-    fits = (wc == 2 or cout % 128 == 0) and nchunks * 32 * wc * 128 + 4 * (128 // wc) * (32 * wc * sz + 16) <= 160 * 1024
+    kc = 128 // sz
+    stored = [(c + 7) // 8 * 8 for c in cins]
+    nchunks = sum(-(-c // kc) for c in stored)
+    lds = nchunks * 32 * wc * 128 + 32 * wc * 4 + 4 * (128 // wc) * (32 * wc * sz + 16)
+    fits = (wc == 2 or cout % 128 == 0) and all(c % kc == 0 for c in stored) and lds <= 160 * 1024 and nchunks <= 8
     if not fits:
         with pytest.raises(RuntimeError):
             eng.set_variant(conv_op, *variant)

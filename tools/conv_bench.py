@@ -57,5 +57,6 @@ if stamps is not None:
     n = st.shape[0]
     tot = st[:, 5].mean()
     print('waves %d, chunks/wave %d, mean wave lifetime %.0f cycles (s_memtime ticks)' % (n, int(st[0, 6]), tot))
-    for name, col in (('top barrier', 0), ('DMA issue', 1), ('DMA wait (vmcnt)', 2), ('data barrier', 3), ('compute', 4)):
-        print('  %-18s %9.0f ticks  %5.1f%%   per chunk %7.0f' % (name, st[:, col].mean(), 100 * st[:, col].mean() / tot, st[:, col].mean() / st[0, 6]))
+    # streaming 1x1 kernel: columns are act + LDS staging / load issue / wait for next stage / LDS read + stores / MFMA
+    for name, col in (('top barrier | staging', 0), ('DMA issue', 1), ('DMA wait (vmcnt)', 2), ('data barrier | stores', 3), ('compute', 4)):
+        print('  %-26s %9.0f ticks  %5.1f%%   per chunk %7.0f' % (name, st[:, col].mean(), 100 * st[:, col].mean() / tot, st[:, col].mean() / st[0, 6]))

@@ -8,9 +8,9 @@ int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const Co
 int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 int conv_launch_f32(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 
-int conv_stream_launch_f16(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
-int conv_stream_launch_bf16(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
-int conv_stream_launch_f32(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
+int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
+int conv_stream_launch_bf16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
+int conv_stream_launch_f32(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
 
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
     const int sz = (int)dtype_size(dtype);
@@ -123,26 +123,30 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, c
 }
 
 int conv_stream_lds(int dtype, int wc, int nchunks, int cb_pack) {
-    if ((wc != 2 && wc != 4) || cb_pack % (32 * wc) != 0) return -1;
+    if ((wc != 2 && wc != 4) || cb_pack % (32 * wc) != 0 || nchunks < 1 || nchunks > 8) return -1;   // 8 = STREAM_MAX_NCH
     const int sz = (int)dtype_size(dtype), cbt = 32 * wc, pxt = 32 * (4 / wc);
-    const long bytes = (long)nchunks * cbt * 128 + 4L * pxt * (cbt * sz + 16);
+    const long bytes = (long)nchunks * cbt * 128 + cbt * 4 + 4L * pxt * (cbt * sz + 16);   // weights, bias, staging
     return bytes <= 160 * 1024 ? (int)bytes : -1;
 }
 
-int conv_stream_launch(int dtype, int wc, int rd, const ConvArgs& a0, int cb_pack, hipStream_t st) {
+int conv_stream_launch(int dtype, int wc, const ConvArgs& a0, int cb_pack, hipStream_t st) {
     // the streaming kernel treats the tensors as [B*H*W][cs] matrices: 1x1, stride 1, dense NHWC output, one phase
     const int nchunks = a0.chunk_begin[a0.nsrc];
     const int lds = conv_stream_lds(dtype, wc, nchunks, cb_pack);
-    if (lds < 0 || (rd != 2 && rd != 3)) return fail(LP_ERR_ARG, "conv1x1 stream: layer does not fit");
+    if (lds < 0) return fail(LP_ERR_ARG, "conv1x1 stream: layer does not fit");
+    if (!a0.trash) return fail(LP_ERR_ARG, "conv1x1 stream: no scratch granule");
     if (a0.nsrc < 1 || a0.nsrc > LP_MAX_SRC || a0.nphase != 1 || a0.out_scale != 1 || a0.Ho != a0.H || a0.Wo != a0.W ||
         a0.out_img_stride != (long long)a0.Ho * a0.Wo * a0.out_pix_stride)
         return fail(LP_ERR_ARG, "conv1x1 stream: not a dense 1x1 stride-1 layer");
+    const int kc = 128 / (int)dtype_size(dtype);
+    for (int i = 0; i < a0.nsrc; ++i)
+        if (a0.src[i].cs % kc != 0) return fail(LP_ERR_ARG, "conv1x1 stream: source channels are not whole 128-byte chunks");
     ConvArgs a = a0;
     a.nct = ceil_div(a.out_c, 32 * wc);
     switch (dtype) {
-        case LP_F16: return conv_stream_launch_f16(wc, rd, a, cb_pack, lds, st);
-        case LP_BF16: return conv_stream_launch_bf16(wc, rd, a, cb_pack, lds, st);
-        case LP_F32: return conv_stream_launch_f32(wc, rd, a, cb_pack, lds, st);
+        case LP_F16: return conv_stream_launch_f16(wc, a, cb_pack, lds, st);
+        case LP_BF16: return conv_stream_launch_bf16(wc, a, cb_pack, lds, st);
+        case LP_F32: return conv_stream_launch_f32(wc, a, cb_pack, lds, st);
     }
     return fail(LP_ERR_ARG, "conv1x1 stream: dtype");
 }

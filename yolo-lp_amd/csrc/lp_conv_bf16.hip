@@ -6,7 +6,7 @@ namespace lp {
 int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
     return launch_dtype<bf16>(cfg, mode, ksize, stride, nbuf, a, st);
 }
-int conv_stream_launch_bf16(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
-    return stream_launch_dtype<bf16>(wc, rd, a, cb_pack, lds, st);
+int conv_stream_launch_bf16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
+    return stream_launch_dtype<bf16>(wc, a, cb_pack, lds, st);
 }
 }  // namespace lp

@@ -6,7 +6,7 @@ namespace lp {
 int conv_launch_f32(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
     return launch_dtype<float>(cfg, mode, ksize, stride, nbuf, a, st);
 }
-int conv_stream_launch_f32(int wc, int rd, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
-    return stream_launch_dtype<float>(wc, rd, a, cb_pack, lds, st);
+int conv_stream_launch_f32(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
+    return stream_launch_dtype<float>(wc, a, cb_pack, lds, st);
 }
 }  // namespace lp

@@ -314,7 +314,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
     const size_t esz = dtype_size(dt);
     std::vector<unsigned char>& blob = e->blob;
     blob.clear();
-    blob.resize(256, 0);   // zero page: DMA source for padding granules (ConvArgs::zero)
+    blob.resize(256, 0);   // bytes 0..127: zero page, DMA source for padding granules (ConvArgs::zero); 128..143: scratch granule (ConvArgs::trash)
     auto align = [&]() { blob.resize((blob.size() + 255) / 256 * 256, 0); };
     // Stem rewrite: a 3x3 stride-2 conv that is the only reader of the network input becomes a 3x3 stride-1 conv over
     // the space-to-depth form of the image (input_s2d_kernel): same sums, a quarter of the halo, no K=27 special case.
@@ -569,6 +569,16 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
 }
 
 // ---- execution ------------------------------------------------------------------------------------------
+// Whether the streaming 1x1 kernel (wc cout tiles per wave) can run the op: dense 1x1 stride-1 conv whose packing has whole
+// cout tiles of the wave, sources made of whole 128-byte K-chunks, resident weights + staging within the LDS.
+static bool stream_fits(const lp_engine* e, const Op& op, int wc) {
+    if (op.kind != OP_CONV || op.ksize != 1 || op.stride != 1 || op.mode != MODE_ACT) return false;
+    const int kc = 128 / (int)dtype_size(e->dtype);
+    for (int i = 0; i < op.nsrc; ++i)
+        if (e->tensors[op.src[i]].cs % kc != 0) return false;
+    return conv_stream_lds(e->dtype, wc, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB) >= 0;
+}
+
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
     ++e->epoch;
@@ -586,6 +596,7 @@ static int prepare_op(lp_engine* e, size_t idx) {
     for (int i = 0; i < op.nsrc; ++i) { a.src[i].ptr = tptr(op.src[i]); a.src[i].cs = e->tensors[op.src[i]].cs; }
     for (int i = 0; i <= LP_MAX_SRC; ++i) a.chunk_begin[i] = op.chunk_begin[i];
     a.zero = e->dev_w;
+    a.trash = e->dev_w + 128;
     a.w = e->dev_w + op.w_off;
     a.bias = (const float*)(e->dev_w + op.b_off);
     const Tensor& s0 = e->tensors[op.src[0]];
@@ -649,7 +660,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
-    if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.stream_rd, L.a, L.cb_pack, st);
+    if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.a, L.cb_pack, st);
     if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
     if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
     ConvArgs a = L.a;
@@ -840,11 +851,11 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             }
         }
         // 1x1 stride-1 layers: the streaming kernel reads the same packing
-        if (op.kind == OP_CONV && op.ksize == 1 && op.stride == 1 && !getenv("LP_NO_STREAM")) {
+        if (!getenv("LP_NO_STREAM")) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.tile = best_tile;
             for (int wc = 2; wc <= 4; wc += 2) {
-                if (conv_stream_lds(e->dtype, wc, op.nchunks, cb) < 0) continue;
-                for (int rd = 2; rd <= 3; ++rd) {
+                if (!stream_fits(e, op, wc)) continue;
+                for (int rd = 2; rd <= 2; ++rd) {
                     op.stream_wc = wc;
                     op.stream_rd = rd;
                     if (prepare_op(e, i) != LP_OK) continue;
@@ -878,7 +889,7 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
     if (cfg == 5 || cfg == 6) {
         const int wc = cfg == 5 ? 2 : 4;
-        if (op.kind != OP_CONV || ks != 1 || stv != 1 || conv_stream_lds(e->dtype, wc, op.nchunks, cb) < 0 || (nbuf != 2 && nbuf != 3))
+        if (!stream_fits(e, op, wc) || nbuf != 2)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the streaming 1x1 kernel does not fit this op");
         op.stream_wc = wc;
         op.stream_rd = nbuf;

@@ -42,7 +42,8 @@ struct ConvArgs {
     const void* w;          // packed [phase][cout_tile][chunk][tap][CB][KC]
     const float* bias;      // [phase?][nct*CB]  (same for every phase)
     unsigned long long* stamps;  // debug builds (-DLP_STAMPS): per-wave phase cycle counters, else null
-    const void* zero;       // >= 16 zero bytes: DMA source of out-of-image / out-of-range granules
+    const void* zero;       // 128 zero bytes: DMA source of out-of-image / out-of-range granules
+    void* trash;            // 16 writable bytes nobody reads: target of stores that must not happen (streaming 1x1 kernel)
     void* out;
     const void* res;        // residual (same dtype/geometry as out) or null
     int res_cs;
@@ -77,10 +78,10 @@ void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, i
 int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 
-// Streaming 1x1 kernel (lp_conv1x1_stream.inc): wc = cout tiles per wave (2 or 4), rd = register ring depth (2 or 3),
-// cb_pack = cout-tile rows of the op's weight packing.  conv_stream_lds() < 0: the layer does not fit.
+// Streaming 1x1 kernel (lp_conv1x1_stream.inc): wc = cout tiles per wave (2 or 4), cb_pack = cout-tile rows of the op's
+// weight packing.  conv_stream_lds() < 0: the layer does not fit.
 int conv_stream_lds(int dtype, int wc, int nchunks, int cb_pack);
-int conv_stream_launch(int dtype, int wc, int rd, const ConvArgs& a, int cb_pack, hipStream_t st);
+int conv_stream_launch(int dtype, int wc, const ConvArgs& a, int cb_pack, hipStream_t st);
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
