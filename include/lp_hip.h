@@ -176,6 +176,20 @@ int lp_preprocess_letterbox(const unsigned char* img, int h0, int w0, void* out,
                             int top, int left, void* stream);
 int lp_rescale_round(float* det, int n, double ratio, double padx, double pady, int img_w, int img_h, void* stream);
 
+/* lp_eval_counts: the matching loops of Evaler.eval (yolov6/core/evaler.py:153-243, box_iou general.py:93-115) for a
+ * batch of images, one workgroup per image.
+ *   det [B,max_det,28] fp32 + det_count [B]: detections as lp_nms returns them (xyxy, 8 corner coords, 8 confs, 8 ids)
+ *   tgt [B,max_t,20] fp32 + tgt_count [B]:   labels (8 ids, xyxy, 8 corner coords), evaler.py:121-128 layout minus column 0
+ *   counts: device int64 [LP_EVAL_NCOUNTS], ACCUMULATED into (zero it before the first batch):
+ *           [LP_EVAL_TRUE] labels, [LP_EVAL_PRED] labels matched with IoU >= 0.7, then four groups of ten 0.05-wide IoU
+ *           bins from 0.5: matched labels, corners right, classes right, both right; [LP_EVAL_UNBINNED] matched labels
+ *           whose IoU fits no bin (IoU >= 1.0f) -- the reference re-uses a stale bin index for those, they are skipped here.
+ * The ratios (evaler.py:245-283) are host arithmetic on these integers. */
+enum { LP_EVAL_TRUE = 0, LP_EVAL_PRED = 1, LP_EVAL_PRED_BINS = 2, LP_EVAL_COR = 12, LP_EVAL_CLS = 22, LP_EVAL_RIGHT = 32,
+       LP_EVAL_UNBINNED = 42, LP_EVAL_NCOUNTS = 43 };
+int lp_eval_counts(const float* det, const int32_t* det_count, int max_det, const float* tgt, const int32_t* tgt_count,
+                   int max_t, int B, long long* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,46 @@ def nhwc(t, cs=None):
 def rel_err(a, b):
     """max |a-b| / max(1, max|b|)"""
     return float((a.double() - b.double()).abs().max() / max(1.0, float(b.double().abs().max())))
+
+
+def unpack_lists(z, prefix, width):
+    """Inverse of tests/golden/make_golden_metric.py::pack: per batch, per image float32 tensors [n, width]."""
+    rows, lens, batch = z[prefix + '_rows'], z[prefix + '_len'].tolist(), z[prefix + '_batch'].tolist()
+    out, o, i = [], 0, 0
+    for b in batch:
+        cur = []
+        for _ in range(b):
+            cur.append(rows[o:o + lens[i]].reshape(-1, width).float().clone())
+            o += lens[i]
+            i += 1
+        out.append(cur)
+    return out
+
+
+def synth_metric_batch(seed, B, max_pred, max_tgt, hw=640.0):
+    """Seeded detections [n,28] / labels [m,20] per image with IoUs spread over the metric's bins (same recipe as the
+    golden generator, kept separate on purpose)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    pb, tb = [], []
+    for _ in range(B):
+        n = 0 if r(1).item() < 0.1 else int(torch.randint(1, max_pred + 1, (1,), generator=g))
+        m = 0 if r(1).item() < 0.1 else int(torch.randint(1, max_tgt + 1, (1,), generator=g))
+        cxy, wh = r(n, 2) * (hw - 120) + 60, r(n, 2) * 80 + 20
+        box = torch.cat([cxy - wh / 2, cxy + wh / 2], 1)
+        cor = torch.cat([box[:, :2], box[:, 2:3], box[:, 1:2], box[:, 2:], box[:, 0:1], box[:, 3:4]], 1) + (r(n, 8) - 0.5) * 4
+        cls = torch.randint(0, 24, (n, 8), generator=g).float()
+        pred = torch.cat([box, cor, r(n, 8), cls], 1)
+        if n > 0 and m > 0:
+            src = torch.randint(0, n, (m,), generator=g)
+            tbox = box[src] + (r(m, 4) - 0.5) * wh[src].repeat(1, 2) * r(m, 1) * 0.9
+            tcor = cor[src] + (r(m, 8) - 0.5) * wh[src].mean(1, keepdim=True) * r(m, 1) * 0.5
+            tcls = cls[src].clone()
+            flip = r(m) < 0.3
+            tcls[flip, 0] = (tcls[flip, 0] + 1) % 24
+            tgt = torch.cat([tcls, tbox, tcor], 1)
+        else:
+            tgt = torch.cat([torch.randint(0, 24, (m, 8), generator=g).float(), r(m, 2) * 300, r(m, 2) * 300 + 320, r(m, 8) * hw], 1)
+        pb.append(pred.float())
+        tb.append(tgt.float())
+    return pb, tb

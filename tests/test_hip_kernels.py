@@ -292,3 +292,70 @@ def test_fused_stem(dtype, xdtype, cout, H, W):
     ref = F.relu(F.conv2d(q(x), q(wt), bias, stride=2, padding=1))
     assert got.shape == ref.shape
     assert rel_err(got, ref) <= TOL[dtype]
+
+
+# ---- LP accuracy metric (lp_eval_counts) -----------------------------------------------------------------------
+def _metric_oracle():
+    import os
+    import sys
+    from conftest import REPO
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    from oracle import lp_metric
+    return lp_metric
+
+
+@pytest.mark.parametrize('case', ['metric_synth_a', 'metric_synth_b', 'metric_crafted'])
+def test_eval_counts_golden(case):
+    """The kernel (through yolov6.utils.lp_metric / Evaler.eval on CUDA tensors) on the inputs of the reference goldens:
+    counters identical to the oracle's, results identical to the reference's Evaler.eval."""
+    from conftest import load_golden
+    from lp_testing import unpack_lists
+    from yolov6.utils import lp_metric
+    from yolov6.core.evaler import Evaler
+    z = load_golden(case)
+    preds, targets = unpack_lists(z, 'pred', 28), unpack_lists(z, 'tgt', 20)
+    ref_c = _metric_oracle().counts([[p.numpy() for p in b] for b in preds], [[t.numpy() for t in b] for b in targets], strict=False)
+    dp = [[p.cuda() for p in b] for b in preds]
+    dt = [[t.cuda() for t in b] for b in targets]
+    assert lp_metric.counts(dp, dt).tolist() == ref_c.tolist()
+    out = Evaler(None, device=torch.device('cuda:0'), half=False).eval(dp, dt, None, 'val')
+    assert out[:5] == z['scalars'].tolist() and out[5] == z['mAP_list'].tolist() and out[6] == z['recall_list'].tolist()
+
+
+@pytest.mark.parametrize('B,max_pred,max_tgt', [(32, 300, 6), (5, 1000, 12), (3, 2, 1)])
+def test_eval_counts_random(B, max_pred, max_tgt):
+    """Bigger seeded batches (more detections than threads of a workgroup) against the oracle; two batches accumulate."""
+    from lp_testing import synth_metric_batch
+    from yolov6.utils import lp_metric
+    M = _metric_oracle()
+    batches = [synth_metric_batch(100 + k, B, max_pred, max_tgt) for k in range(2)]
+    preds, targets = [b[0] for b in batches], [b[1] for b in batches]
+    ref_c = M.counts([[p.numpy() for p in b] for b in preds], [[t.numpy() for t in b] for b in targets], strict=False)
+    got = lp_metric.counts([[p.cuda() for p in b] for b in preds], [[t.cuda() for t in b] for b in targets])
+    assert got.tolist() == ref_c.tolist()
+    assert int(ref_c[M.I_PRED_BINS:M.I_PRED_BINS + 10].sum()) > 0          # the case exercises the bins
+
+
+def test_eval_counts_edges():
+    """Identical boxes (IoU 1: no bin), duplicate detections (first index wins), empty images, argument checks."""
+    from yolov6.hip import runtime
+    from yolov6.utils import lp_metric
+    M = _metric_oracle()
+    pred = torch.zeros(3, 28)
+    pred[:, :4] = torch.tensor([[10., 10., 50., 30.], [10., 10., 50., 30.], [100., 100., 140., 120.]])
+    pred[0, 20:] = 1.0                       # detection 0 has the right classes, its duplicate 1 does not
+    tgt = torch.zeros(2, 20)
+    tgt[:, :8] = 1.0
+    tgt[0, 8:12] = torch.tensor([10., 10., 50., 29.])      # IoU 0.95 with detections 0 and 1
+    tgt[0, 12:] = pred[0, 4:12]
+    tgt[1, 8:12] = pred[2, :4]                              # IoU 1.0: unbinned
+    preds = [[pred, torch.zeros(0, 28)], [torch.zeros(0, 28)]]
+    targets = [[tgt, tgt[:1]], [torch.zeros(0, 20)]]
+    ref_c = M.counts([[p.numpy() for p in b] for b in preds], [[t.numpy() for t in b] for b in targets], strict=False)
+    got = lp_metric.counts([[p.cuda() for p in b] for b in preds], [[t.cuda() for t in b] for b in targets])
+    assert got.tolist() == ref_c.tolist()
+    assert int(got[lp_metric.UNBINNED]) == 1 and int(got[lp_metric.RIGHT + 9]) == 1 and int(got[lp_metric.TRUE]) == 3
+    with pytest.raises(ValueError):
+        runtime.eval_counts(torch.zeros(2, 4, 28, device='cuda'), torch.zeros(2, dtype=torch.int32, device='cuda'),
+                            torch.zeros(3, 1, 20, device='cuda'), torch.zeros(3, dtype=torch.int32, device='cuda'))

@@ -11,7 +11,8 @@ import torch
 from conftest import load_golden, REPO
 
 sys.path.insert(0, os.path.join(REPO))
-from oracle import lp_oracle, lp_post  # noqa: E402
+from oracle import lp_oracle, lp_post, lp_metric as metric_oracle  # noqa: E402
+from lp_testing import unpack_lists  # noqa: E402
 
 MODEL_CASES = [('lps_tiny_128x96', 'lps_tiny_weights', 'yololps'),
                ('lps_tiny_64x160', 'lps_tiny_weights', 'yololps'),
@@ -116,3 +117,68 @@ def test_full_size_digest(name):
         pred, _ = m(x)
     torch.testing.assert_close(pred[0, g['rows']], g['pred_rows'], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(pred[0].double().sum(0), g['colsum'], rtol=1e-6, atol=1e-4)
+
+
+METRIC_CASES = ['metric_synth_a', 'metric_synth_b', 'metric_crafted']
+
+
+@pytest.mark.parametrize('case', METRIC_CASES)
+def test_lp_metric_oracle_matches_reference(case):
+    """oracle/lp_metric.py against the outputs of the reference's own Evaler.eval (tests/golden/make_golden_metric.py)."""
+    z = load_golden(case)
+    preds, targets = unpack_lists(z, 'pred', 28), unpack_lists(z, 'tgt', 20)
+    out = metric_oracle.evaluate([[p.numpy() for p in b] for b in preds], [[t.numpy() for t in b] for b in targets])
+    assert out[:5] == z['scalars'].tolist()               # python floats from integer ratios: exact
+    assert out[5] == z['mAP_list'].tolist() and out[6] == z['recall_list'].tolist()
+
+
+@pytest.mark.parametrize('case', METRIC_CASES)
+def test_lp_metric_mirror_cpu_matches_reference(case):
+    """yolov6.utils.lp_metric (vectorised CPU path) and Evaler.eval of the mirror: same counters as the oracle, same
+    seven results as the reference."""
+    from yolov6.utils import lp_metric
+    from yolov6.core.evaler import Evaler
+    z = load_golden(case)
+    preds, targets = unpack_lists(z, 'pred', 28), unpack_lists(z, 'tgt', 20)
+    c = lp_metric.counts(preds, targets)
+    ref_c = metric_oracle.counts([[p.numpy() for p in b] for b in preds], [[t.numpy() for t in b] for b in targets], strict=False)
+    assert c.tolist() == ref_c.tolist()
+    ev = Evaler(None, device=torch.device('cpu'), half=False)
+    out = ev.eval(preds, targets, None, 'val')
+    assert out[:5] == z['scalars'].tolist() and out[5] == z['mAP_list'].tolist() and out[6] == z['recall_list'].tolist()
+
+
+def test_lp_metric_unbinned_labels_are_reported():
+    """IoU == 1 fits no bin: the reference re-uses a stale bin index (or raises); oracle strict mode does the same, the
+    batched implementations skip the label and count it."""
+    from yolov6.utils import lp_metric
+    pred = torch.zeros(1, 28)
+    pred[0, :4] = torch.tensor([10., 10., 50., 30.])
+    tgt = torch.zeros(1, 20)
+    tgt[0, 8:12] = pred[0, :4]
+    c = lp_metric.counts([[pred]], [[tgt]])
+    assert int(c[lp_metric.UNBINNED]) == 1 and int(c[lp_metric.PRED]) == 1 and int(c[lp_metric.TRUE]) == 1
+    assert c[lp_metric.PRED_BINS:lp_metric.UNBINNED].sum() == 0
+    with pytest.raises(UnboundLocalError):
+        metric_oracle.counts([[pred.numpy()]], [[tgt.numpy()]], strict=True)
+    assert metric_oracle.counts([[pred.numpy()]], [[tgt.numpy()]], strict=False).tolist() == c.tolist()
+
+
+def test_evaler_split_targets_matches_reference_loop():
+    """Evaler.split_targets against the reference's per-row python loop (evaler.py:120-128) restated here."""
+    from yolov6.core.evaler import Evaler
+    from yolov6.utils.nms import xywh2xyxy
+    g = torch.Generator().manual_seed(3)
+    T, B, h, w = 9, 4, 96, 160
+    targets = torch.rand(T, 21, generator=g)
+    targets[:, 0] = torch.tensor([0, 0, 2, 3, 3, 3, 0, 2, 3]).float()
+    exp_t = targets.clone()
+    exp_t[:, 9:13] = xywh2xyxy(exp_t[:, 9:13])
+    exp = [torch.zeros((0, 20))] * B
+    for row in exp_t:
+        for j in range(9, 21, 2):
+            row[j] = row[j] * w
+            row[j + 1] = row[j + 1] * h
+        exp[int(row[0])] = torch.cat((exp[int(row[0])], row[None, 1:]), dim=0)
+    got = Evaler(None, device=torch.device('cpu'), half=False).split_targets(targets, B, h, w)
+    assert len(got) == B and all(torch.equal(a, b) for a, b in zip(got, exp))

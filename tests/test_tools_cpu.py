@@ -81,6 +81,33 @@ def test_eval_speed_cli_cpu(workdir):
     _make_checkpoint(str(ckpt))
     for i in range(3):
         _make_image(str(img_dir / ('f%d.png' % i)), 240, 320, i)
-    preds, speed = ev.run(str(img_dir), weights=str(ckpt), batch_size=2, img_size=128, conf_thres=0.4, iou_thres=0.45,
-                          task='speed', device='cpu', half=False, save_dir=str(workdir / 'val'), name='exp')
-    assert sum(len(b) for b in preds) == 3 and all(v >= 0 for v in speed)
+    preds, speed, metrics = ev.run(str(img_dir), weights=str(ckpt), batch_size=2, img_size=128, conf_thres=0.4, iou_thres=0.45,
+                                   task='speed', device='cpu', half=False, save_dir=str(workdir / 'val'), name='exp')
+    assert sum(len(b) for b in preds) == 3 and all(v >= 0 for v in speed) and metrics is None
+
+
+def test_eval_val_cli_reads_labels_and_reports_the_lp_metric(workdir):
+    """--task val: label files beside the images go through the reference's letterbox transform and Evaler.eval."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import importlib
+    import numpy as np
+    ev = importlib.import_module('eval')
+    ckpt = workdir / 'tiny.pt'
+    img_dir, lab_dir = workdir / 'ds' / 'images' / 'val', workdir / 'ds' / 'labels' / 'val'
+    img_dir.mkdir(parents=True)
+    lab_dir.mkdir(parents=True)
+    _make_checkpoint(str(ckpt))
+    for i in range(3):
+        _make_image(str(img_dir / ('f%d.png' % i)), 240, 320, i)
+    row = [1, 2, 3, 4, 5, 6, 7, 8, 0.5, 0.5, 0.25, 0.2, 0.375, 0.4, 0.625, 0.4, 0.625, 0.6, 0.375, 0.6]
+    (lab_dir / 'f0.txt').write_text(' '.join(str(v) for v in row) + '\n' + ' '.join(str(v) for v in row) + '\n')
+    (lab_dir / 'f2.txt').write_text(' '.join(str(v) for v in row) + '\n')
+    # letterbox of a 240x320 frame into 128x128: ratio 0.4, content 96x128 at top 16
+    lab = ev.letterbox_labels(np.array([row], dtype=np.float32), 240, 320, 0.4, (0.0, 16.0), 128, 128)
+    assert np.allclose(lab[0, 8:12], [0.5, 0.5, 0.25, 0.2 * 96 / 128], atol=1e-6)
+    assert np.allclose(lab[0, 12:14], [0.375, (0.4 * 96 + 16) / 128], atol=1e-6)
+    batches = list(ev.image_batches(str(img_dir), 128, 2))
+    assert [b[1].shape for b in batches] == [(2, 21), (1, 21)] and batches[1][1][0, 0] == 0
+    preds, speed, metrics = ev.run(str(img_dir), weights=str(ckpt), batch_size=2, img_size=128, conf_thres=0.03, iou_thres=0.65,
+                                   task='val', device='cpu', half=False, save_dir=str(workdir / 'val'), name='exp')
+    assert metrics is not None and len(metrics) == 7 and len(metrics[5]) == 10 and 0.0 <= metrics[4] <= 1.0

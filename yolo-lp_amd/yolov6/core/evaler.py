@@ -3,8 +3,8 @@ yolov6/core/evaler.py:67-151, 507-513, 578-608).
 
 ``predict`` is a caller of the hot path and keeps the reference's protocol: pre-process (to device, cast,
 /255), inference (``outputs, _ = model(imgs)``), NMS (``multi_label=True``, max_det 300), each bracketed by
-``time_sync``.  The LP accuracy metric loops (reference :153-283) are CPU bookkeeping outside the hot-path
-scope and are not mirrored: ``eval`` reports the speed figures only.
+``time_sync``.  ``eval`` (reference :153-283) reports the speed figures and the LP accuracy metric; its matching
+loops run as one kernel launch per batch (``yolov6.utils.lp_metric``).
 """
 import os
 
@@ -12,7 +12,8 @@ import torch
 
 from yolov6.utils.events import LOGGER
 from yolov6.utils.checkpoint import load_checkpoint
-from yolov6.utils.nms import non_max_suppression
+from yolov6.utils.nms import non_max_suppression, xywh2xyxy
+from yolov6.utils import lp_metric
 from yolov6.utils.torch_utils import time_sync, get_model_info
 
 
@@ -44,14 +45,19 @@ class Evaler:
         return model
 
     def predict(self, model, dataloader, task):
-        """dataloader yields (imgs uint8 [B,3,H,W], targets, paths, shapes); returns the per-batch detections."""
+        """dataloader yields (imgs uint8 [B,3,H,W], targets [T,21] or None, paths, shapes).  Returns, like the reference
+        (:103-151), (pred_results, total_targets, vis_outputs, vis_imgs): per batch the per-image detections [n,28] and
+        labels [m,20] (8 ids, xyxy box and 8 corner coordinates in pixels of the network input)."""
         self.speed_result = torch.zeros(4, device=self.device)
-        pred_results = []
-        for imgs, targets, paths, shapes in dataloader:
+        pred_results, total_targets = [], []
+        vis_outputs, vis_imgs = [], None
+        for i, (imgs, targets, paths, shapes) in enumerate(dataloader):
+            c, h, w = imgs.shape[1:]
             t1 = time_sync()
             imgs = imgs.to(self.device, non_blocking=True)
             imgs = imgs.half() if self.half else imgs.float()
             imgs /= 255
+            batch_targets = self.split_targets(targets, imgs.shape[0], h, w)
             self.speed_result[1] += time_sync() - t1
             t2 = time_sync()
             outputs, _ = model(imgs)
@@ -61,7 +67,37 @@ class Evaler:
             self.speed_result[3] += time_sync() - t3
             self.speed_result[0] += len(outputs)
             pred_results.append(outputs)
-        return pred_results
+            total_targets.append(batch_targets)
+            if i == 0:
+                vis_num = min(len(imgs), 8)
+                vis_outputs, vis_imgs = outputs[:vis_num], imgs[:vis_num]
+        return pred_results, total_targets, vis_outputs, vis_imgs
+
+    def split_targets(self, targets, batch, h, w):
+        """Reference :120-128: labels [T,21] = (image index, 8 ids, xywh box, 8 corner coords), all normalised ->
+        per image [m,20] with the box as xyxy and every coordinate in pixels (x * w, y * h)."""
+        out = [torch.zeros((0, 20), device=self.device) for _ in range(batch)]
+        if targets is None or len(targets) == 0:
+            return out
+        targets = targets.to(self.device).float().clone()
+        targets[:, 9:13] = xywh2xyxy(targets[:, 9:13])
+        targets[:, 9:21:2] *= w
+        targets[:, 10:21:2] *= h
+        idx = targets[:, 0].long()
+        for b in range(batch):
+            out[b] = targets[idx == b, 1:]
+        return out
+
+    def eval(self, preds, targets, model=None, task='val'):
+        """Reference :153-283: speed report, then [mAP, mAP_50, mAP_75, mAP_50_95, recall, mAP_list, recall_list]."""
+        if hasattr(self, 'speed_result'):
+            self.eval_speed(task)
+        assert len(preds) == len(targets), 'predict imgs count is not match with targets!'
+        c = lp_metric.counts(preds, targets)
+        if int(c[lp_metric.UNBINNED]):
+            LOGGER.warning('%d matched labels have IoU >= 1.0 and fit no IoU bin: skipped (the reference re-uses a stale bin '
+                           'index for them)' % int(c[lp_metric.UNBINNED]))
+        return lp_metric.finish(c)
 
     def eval_speed(self, task):
         """ms per image for pre-process / inference / NMS, like the reference's --task speed report."""

@@ -10,6 +10,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 LP_F16, LP_BF16, LP_F32 = 0, 1, 2
 LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
 LP_PRED_COLS, LP_DET_COLS, LP_MAX_SRC = 290, 28, 4
+LP_EVAL_NCOUNTS = 43   # lp_eval_counts: length of the counts vector (include/lp_hip.h)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # .../yolo-lp_amd
 LIB_PATH = os.environ.get('LP_HIP_LIB') or os.path.join(_PKG_ROOT, 'libyololp_hip.so')   # LP_HIP_LIB: debug builds
@@ -57,6 +58,7 @@ SYMBOLS = {
     'lp_preprocess_letterbox': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     'lp_rescale_round': (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, c_void_p]),
+    'lp_eval_counts': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_size_t, c_void_p]),
 }

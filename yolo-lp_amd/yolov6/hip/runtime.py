@@ -481,3 +481,27 @@ def rescale_round(ori_shape, det, target_shape):
                                               ctypes.c_void_p(torch.cuda.current_stream(det.device).cuda_stream)),
                   'lp_rescale_round')
     return det
+
+
+def eval_counts(det, det_count, tgt, tgt_count, counts=None):
+    """Counters of the LP accuracy metric for one batch (``lp_eval_counts``): det [B,max_det,28] fp32 + det_count [B]
+    int32 as ``nms_padded`` returns them, tgt [B,max_t,20] fp32 + tgt_count [B] int32; ``counts`` (int64 [43], CUDA) is
+    accumulated into and returned (allocated zeroed when None)."""
+    dev = det.device
+    ok = (det.is_cuda and det.dtype == torch.float32 and det.dim() == 3 and det.shape[2] == abi.LP_DET_COLS and det.is_contiguous()
+          and tgt.dtype == torch.float32 and tgt.dim() == 3 and tgt.shape[2] == 20 and tgt.is_contiguous() and tgt.device == dev
+          and det_count.dtype == torch.int32 and tgt_count.dtype == torch.int32 and det_count.is_contiguous() and tgt_count.is_contiguous()
+          and det_count.device == dev and tgt_count.device == dev
+          and det.shape[0] == tgt.shape[0] == det_count.numel() == tgt_count.numel())
+    if not ok:
+        raise ValueError('eval_counts: expected contiguous CUDA det [B,D,28] / tgt [B,T,20] fp32 and int32 counts [B] on one device')
+    if counts is None:
+        counts = torch.zeros(abi.LP_EVAL_NCOUNTS, dtype=torch.int64, device=dev)
+    elif not (counts.dtype == torch.int64 and counts.numel() == abi.LP_EVAL_NCOUNTS and counts.device == dev and counts.is_contiguous()):
+        raise ValueError('eval_counts: counts must be a contiguous CUDA int64 [%d] tensor' % abi.LP_EVAL_NCOUNTS)
+    with torch.cuda.device(dev):
+        abi.check(abi.load().lp_eval_counts(ctypes.c_void_p(det.data_ptr()), ctypes.c_void_p(det_count.data_ptr()), det.shape[1],
+                                            ctypes.c_void_p(tgt.data_ptr()), ctypes.c_void_p(tgt_count.data_ptr()), tgt.shape[1],
+                                            det.shape[0], ctypes.c_void_p(counts.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'lp_eval_counts')
+    return counts
