@@ -28,12 +28,19 @@ class Arch:
     """Static description of one model (what configs/*.py + yolo.py:54-67 resolve to)."""
 
     def __init__(self, name, depth, width, csp=False, csp_e=0.5, cspsppf=True, use_dfl=False, reg_max=0,
-                 npro=31, nalp=24, nads=37):
+                 npro=31, nalp=24, nads=37, p6=False, bifusion=True, csp_neck=None):
         self.name, self.csp, self.csp_e, self.cspsppf = name, csp, csp_e, cspsppf
         self.use_dfl, self.reg_max = use_dfl, reg_max
         self.npro, self.nalp, self.nads = npro, nalp, nads
-        reps = [1, 6, 12, 18, 6, 12, 12, 12, 12]
-        chans = [64, 128, 256, 512, 1024, 256, 128, 128, 256, 256, 512]
+        self.csp_neck = csp if csp_neck is None else csp_neck      # a CSP neck on a Rep backbone gets csp_e = 0.5 (yolo.py:96-100)
+        self.csp_e_neck = csp_e if csp else 0.5
+        self.p6, self.bifusion = p6, bifusion      # P6: sixth backbone stage + four head levels; bifusion False: plain PAN neck
+        if p6:      # configs/yolov6{n,s,m,l}6.py
+            reps = [1, 6, 12, 18, 6, 6, 12, 12, 12, 12, 12, 12]
+            chans = [64, 128, 256, 512, 768, 1024, 512, 256, 128, 256, 512, 1024]
+        else:
+            reps = [1, 6, 12, 18, 6, 12, 12, 12, 12]
+            chans = [64, 128, 256, 512, 1024, 256, 128, 128, 256, 256, 512]
         self.repeats = [(max(round(i * depth), 1) if i > 1 else i) for i in reps]      # yolo.py:65
         self.channels = [math.ceil(i * width / 8) * 8 for i in chans]                   # yolo.py:66
         self.no = npro + nalp + 5 * nads + 13                                           # effidehead.py:21
@@ -43,13 +50,17 @@ ARCHS = {
     'yololps': dict(depth=0.33, width=0.50),
     'yololpn': dict(depth=0.33, width=0.25),
     'yolov6m': dict(depth=0.60, width=0.75, csp=True, csp_e=2.0 / 3, cspsppf=False, use_dfl=True, reg_max=16),
+    # P6 / plain-PAN variants: stock YOLOv6 assemblies with the LP head
+    'yolov6s6': dict(depth=0.33, width=0.50, p6=True),
+    'yolov6m6': dict(depth=0.60, width=0.75, csp=True, csp_e=2.0 / 3, cspsppf=False, use_dfl=True, reg_max=16, p6=True),
 }
 
 
-def arch(name, width=None):
+def arch(name, width=None, **overrides):
     kw = dict(ARCHS[name])
     if width is not None:
         kw['width'] = width
+    kw.update(overrides)
     return Arch(name, **kw)
 
 
@@ -171,41 +182,60 @@ def bifusion(sd, p, x0, x1, x2):
 # network
 # --------------------------------------------------------------------------
 def backbone(sd, a, x):
-    """EfficientRep.forward / CSPBepBackbone.forward (efficientrep.py:103-117, :350-364)."""
+    """EfficientRep(6).forward / CSPBepBackbone(_P6).forward (efficientrep.py:103-117, :229-246, :350-364, :481-497)."""
     def body(p, t, n):
         return bepc3(sd, p, t, n) if a.csp else rep_stage(sd, p, t, n)
 
     x = rep(sd, 'backbone.stem', x, 2)
     outs = []
-    for i in (2, 3, 4, 5):
+    last = 6 if a.p6 else 5
+    for i in range(2, last + 1):
         p = 'backbone.ERBlock_%d' % i
         x = body(p + '.1', rep(sd, p + '.0', x, 2), a.repeats[i - 1])
-        if i == 5:
+        if i == last:
             x = sim_cspsppf(sd, p + '.2', x) if a.cspsppf else sim_sppf(sd, p + '.2', x)
         outs.append(x)
-    return outs          # (P2, P3, P4, P5)
+    return outs if a.bifusion else outs[1:]          # (P2,) P3, P4, P5 (, P6): the plain PAN necks run with fuse_P2=False
 
 
 def neck(sd, a, feats):
-    """RepBiFPANNeck.forward / CSPRepBiFPANNeck.forward (reppan.py:214-236, :746-768)."""
+    """The eight necks of reppan.py: BiFusion or transpose-conv + concat on the way down, P5 (three levels out) or P6
+    (four); forward passes at :108-128, :214-236, :364-390, :514-541, :635-655, :746-768, :900-928, :1053-1083."""
     def stage(p, t, n):
-        return bepc3(sd, 'neck.' + p, t, n) if a.csp else rep_stage(sd, 'neck.' + p, t, n)
+        return bepc3(sd, 'neck.' + p, t, n) if a.csp_neck else rep_stage(sd, 'neck.' + p, t, n)
 
-    x3, x2, x1, x0 = feats
+    def up(i, t):      # Transpose.forward (common.py:186-187)
+        return F.conv_transpose2d(t, sd['neck.upsample%d.upsample_transpose.weight' % i],
+                                  sd['neck.upsample%d.upsample_transpose.bias' % i], stride=2)
+
     r = a.repeats
-    fpn0 = cba(sd, 'neck.reduce_layer0', x0)
-    f0 = stage('Rep_p4', bifusion(sd, 'neck.Bifusion0', fpn0, x1, x2), r[5])
-    fpn1 = cba(sd, 'neck.reduce_layer1', f0)
-    pan2 = stage('Rep_p3', bifusion(sd, 'neck.Bifusion1', fpn1, x2, x3), r[6])
-    pan1 = stage('Rep_n3', torch.cat([cba(sd, 'neck.downsample2', pan2, 2), fpn1], 1), r[7])
-    pan0 = stage('Rep_n4', torch.cat([cba(sd, 'neck.downsample1', pan1, 2), fpn0], 1), r[8])
-    return [pan2, pan1, pan0]
+    feats = list(feats)
+    nlev = 4 if a.p6 else 3
+    base = 6 if a.p6 else 5                      # index of the first neck entry in the repeats list
+    names_p = ['Rep_p5', 'Rep_p4', 'Rep_p3'] if a.p6 else ['Rep_p4', 'Rep_p3']
+    names_n = ['Rep_n4', 'Rep_n5', 'Rep_n6'] if a.p6 else ['Rep_n3', 'Rep_n4']
+    down = ['downsample2', 'downsample1', 'downsample0'] if a.p6 else ['downsample2', 'downsample1']
+    x = feats[-1]
+    fpn = []
+    for k in range(nlev - 1):                    # top-down
+        f = cba(sd, 'neck.reduce_layer%d' % k, x)
+        fpn.append(f)
+        if a.bifusion:       # inputs: reduced map, the backbone level below, and the one below that
+            t = bifusion(sd, 'neck.Bifusion%d' % k, f, feats[-2 - k], feats[-3 - k])
+        else:
+            t = torch.cat([up(k, f), feats[-2 - k]], 1)
+        x = stage(names_p[k], t, r[base + k])
+    outs = [x]
+    for k in range(nlev - 1):                    # bottom-up
+        x = stage(names_n[k], torch.cat([cba(sd, 'neck.' + down[k], x, 2), fpn[-1 - k]], 1), r[base + nlev - 1 + k])
+        outs.append(x)
+    return outs
 
 
 CLS_HEADS = ('pro', 'alp', 'ad0', 'ad1', 'ad2', 'ad3', 'ad4', 'ad5')
 
 
-def anchors(shapes, strides=(8, 16, 32)):
+def anchors(shapes, strides=(8, 16, 32, 64)):
     """generate_anchors(is_eval=True, mode='af') (anchor_generator.py:11-31)."""
     pts, st = [], []
     for (h, w), s in zip(shapes, strides):

@@ -84,6 +84,55 @@ def test_tiny_model_half_precision(case, weights, name, dtype, box_tol, prob_tol
     _check_pred(pred.cpu(), g['pred'], max(g['x'].shape[2:]), box_tol, prob_tol, '%s %s' % (dtype, case))
 
 
+# P6 and plain-PAN assemblies (tests/golden/make_golden_p6.py): (case, config, build overrides)
+P6_CASES = [
+    ('s6_tiny_128x192', 'yolov6s6', {}),
+    ('m6_tiny_128x64', 'yolov6m6', {}),
+    ('s6pan_tiny_64x128', 'yolov6s6', dict(neck='RepPANNeck6', fuse_P2=False)),
+    ('s6csppan_tiny_128x128', 'yolov6s6', dict(neck='CSPRepPANNeck_P6', fuse_P2=False)),
+    ('span_tiny_96x64', 'yololps', dict(neck='RepPANNeck', fuse_P2=False)),
+    ('mpan_tiny_64x96', 'yolov6m', dict(neck='CSPRepPANNeck', fuse_P2=False)),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('case,name,build_kw', P6_CASES, ids=[c[0] for c in P6_CASES])
+def test_p6_and_pan_models_match_reference_golden(case, name, build_kw, dtype):
+    """Four-level (stride 64) heads, six-stage backbones and the transpose-conv + concat necks through the engine,
+    against the outputs of the reference's own model code (deploy-fused weights, fp32 within 1e-4 of the extent)."""
+    from yolov6.utils.synth import build_synthetic
+    from yolov6.utils.torch_utils import fuse_model
+    from yolov6.layers.common import RepVGGBlock
+    g, sd = load_golden(case), load_golden(case + '_weights')
+    m = build_synthetic(CFG(name), width=0.0625, depth=0.25, sigma=1.5, **build_kw)
+    m.load_state_dict(sd)
+    m = fuse_model(m).eval()
+    for layer in m.modules():
+        if isinstance(layer, RepVGGBlock):
+            layer.switch_to_deploy()
+    m = m.cuda().to(dtype)
+    x = g['x']
+    with torch.no_grad():
+        pred, feats = m(x.cuda().to(dtype))
+    nlev = len([k for k in g if k.startswith('neck')])
+    assert len(feats) == nlev and pred.shape == g['pred'].shape
+    if dtype == torch.float32:
+        _check_pred(pred.cpu(), g['pred'], max(x.shape[2:]), 1e-4, 1e-4, 'fp32 %s' % case)
+        for i, f in enumerate(feats):
+            assert rel_err(f.float().cpu(), g['neck%d' % i]) <= 1e-4
+    else:
+        _check_pred(pred.cpu(), g['pred'], max(x.shape[2:]), 2e-2, 2e-2, 'f16 %s' % case)
+
+
+def test_p6_engine_needs_multiples_of_64():
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yolov6s6'), width=0.0625, depth=0.25).cuda()
+    with torch.no_grad():
+        m(torch.zeros(1, 3, 128, 64, device='cuda'))
+        with pytest.raises(ValueError, match='coarsest stride'):
+            m(torch.zeros(1, 3, 96, 64, device='cuda'))
+
+
 @pytest.mark.parametrize('name,B,H,W', [('yololps', 2, 640, 640), ('yololpn', 3, 640, 416), ('yolov6m', 1, 320, 320)])
 def test_full_model_fp32_vs_oracle(name, B, H, W):
     from oracle import lp_oracle

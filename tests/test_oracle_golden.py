@@ -17,6 +17,15 @@ from lp_testing import unpack_lists  # noqa: E402
 MODEL_CASES = [('lps_tiny_128x96', 'lps_tiny_weights', 'yololps'),
                ('lps_tiny_64x160', 'lps_tiny_weights', 'yololps'),
                ('v6m_tiny_96x128', 'v6m_tiny_weights', 'yolov6m')]
+# P6 and plain-PAN assemblies (tests/golden/make_golden_p6.py): (case, config, oracle arch overrides, build overrides)
+P6_CASES = [
+    ('s6_tiny_128x192', 'yolov6s6', {}, {}),
+    ('m6_tiny_128x64', 'yolov6m6', {}, {}),
+    ('s6pan_tiny_64x128', 'yolov6s6', dict(bifusion=False), dict(neck='RepPANNeck6', fuse_P2=False)),
+    ('s6csppan_tiny_128x128', 'yolov6s6', dict(bifusion=False, csp_neck=True), dict(neck='CSPRepPANNeck_P6', fuse_P2=False)),
+    ('span_tiny_96x64', 'yololps', dict(bifusion=False), dict(neck='RepPANNeck', fuse_P2=False)),
+    ('mpan_tiny_64x96', 'yolov6m', dict(bifusion=False), dict(neck='CSPRepPANNeck', fuse_P2=False)),
+]
 NMS_CASES = ['nms_model_tiny', 'nms_synth_600', 'nms_synth_maxdet5', 'nms_synth_obj', 'nms_crafted', 'nms_empty']
 
 
@@ -58,6 +67,38 @@ def test_forward_mirror_cpu_is_bit_exact(case, weights, name):
         torch.set_num_threads(nthreads)
     assert torch.equal(pred, g['pred'])
     for i in range(3):
+        assert torch.equal(feats[i], g['neck%d' % i])
+
+
+@pytest.mark.parametrize('case,name,arch_kw,build_kw', P6_CASES, ids=[c[0] for c in P6_CASES])
+def test_p6_and_pan_oracle_and_mirror_match_reference(case, name, arch_kw, build_kw):
+    """The six other assemblies of the reference (P6 backbones / necks, plain PAN necks): oracle within the fused-vs-
+    unfused floor, mirror bit-exact (same seeded weights, same ops in the same order)."""
+    from yolov6.utils.synth import build_synthetic
+    g, sd = load_golden(case), load_golden(case + '_weights')
+    a = lp_oracle.arch(name, width=0.0625, depth=0.25, **arch_kw)
+    pred, neck = lp_oracle.forward(sd, a, g['x'])
+    nlev = 4 if a.p6 else 3
+    assert len(neck) == nlev
+    for i in range(nlev):
+        torch.testing.assert_close(neck[i], g['neck%d' % i], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pred, g['pred'], rtol=1e-4, atol=1e-3)
+    m = build_synthetic(os.path.join(REPO, 'configs', name + '.py'), width=0.0625, depth=0.25, sigma=1.5, **build_kw)
+    msd = m.state_dict()
+    assert list(msd.keys()) == list(sd.keys())
+    for k in sd:
+        if sd[k].is_floating_point():
+            assert torch.equal(msd[k].half().float(), sd[k]), k
+    m.load_state_dict(sd)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(4)
+    try:
+        with torch.no_grad():
+            mp, feats = m(g['x'].clone())
+    finally:
+        torch.set_num_threads(nthreads)
+    assert torch.equal(mp, g['pred'])
+    for i in range(nlev):
         assert torch.equal(feats[i], g['neck%d' % i])
 
 

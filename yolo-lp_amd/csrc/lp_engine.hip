@@ -486,14 +486,25 @@ static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>
     return off + 256;
 }
 
+// H and W must be multiples of the coarsest stride of the graph (32; 64 with a P6 level), at least 32
+static int size_granule(const lp_engine* e) {
+    int sl = 5;
+    for (const Tensor& t : e->tensors) sl = t.sl > sl ? t.sl : sl;
+    return 1 << sl;
+}
+
 extern "C" size_t lp_engine_arena_bytes(const lp_engine* e, int B, int H, int W) {
-    if (!e || B < 1 || H < 32 || W < 32 || (H & 31) || (W & 31)) return 0;
+    if (!e || B < 1) return 0;
+    const int g = size_granule(e);
+    if (H < g || W < g || H % g || W % g) return 0;
     return place(e, B, H, W, nullptr);
 }
 
 extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B, int H, int W) {
     if (!e || !e->finalized) return fail(LP_ERR_STATE, "lp_engine_bind: finalize first");
-    if (B < 1 || H < 32 || W < 32 || (H & 31) || (W & 31)) return fail(LP_ERR_ARG, "lp_engine_bind: H and W must be positive multiples of 32");
+    const int gran = size_granule(e);
+    if (B < 1 || H < gran || W < gran || H % gran || W % gran)
+        return fail(LP_ERR_ARG, "lp_engine_bind: H and W must be positive multiples of " + std::to_string(gran) + " (the coarsest stride of the graph)");
     if (!dev_arena || ((uintptr_t)dev_arena & 255)) return fail(LP_ERR_ARG, "lp_engine_bind: need a 256-byte aligned device pointer");
     const size_t need = place(e, B, H, W, nullptr);
     if (bytes < need) return fail(LP_ERR_ARG, "lp_engine_bind: arena too small");

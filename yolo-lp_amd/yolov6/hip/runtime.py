@@ -236,32 +236,60 @@ class Engine:
         self.lane(0)
         return self.cba(m.cv3, [up, a, d], sl0 - 1)
 
+    def upsample(self, m, x, sl):
+        """Transpose (common.py:174-187): 2x2 stride-2 transposed conv of a map at stride level ``sl``."""
+        t = m.upsample_transpose
+        up = self.tensor(t.out_channels, sl - 1)
+        abi.check(self.lib.lp_engine_add_deconv2x2(self.h, x, up, self._ptr(_f32(t.weight)), self._ptr(_f32(t.bias))),
+                  'lp_engine_add_deconv2x2')
+        return up
+
     def _build(self, model):
         bb, nk, det = model.backbone, model.neck, model.detect
-        if not getattr(bb, 'fuse_P2', False):
-            raise NotImplementedError('the BiFPAN necks need the P2 output (fuse_P2=True)')
+        p6 = hasattr(bb, 'ERBlock_6')
+        last = 6 if p6 else 5
         x = self.basic(bb.stem, [self.input_id], 0)
         feats = []
-        for i, sl in zip((2, 3, 4, 5), (1, 2, 3, 4)):          # sl = stride log2 of the stage input
+        for i in range(2, last + 1):                              # ERBlock_i takes stride 2^(i-1) to 2^i
             st = getattr(bb, 'ERBlock_%d' % i)
-            x = self.basic(st[0], [x], sl)
-            x = self.stage(st[1], [x], sl + 1)
+            x = self.basic(st[0], [x], i - 1)
+            x = self.stage(st[1], [x], i)
             if len(st) > 2:
-                x = self.merge_layer(st[2], x, sl + 1)
+                x = self.merge_layer(st[2], x, i)
             feats.append(x)
-        x3, x2, x1, x0 = feats                                    # strides 4, 8, 16, 32  (reppan.py:216)
-        fpn0 = self.cba(nk.reduce_layer0, [x0], 5)
-        f0 = self.stage(nk.Rep_p4, [self.bifusion(nk.Bifusion0, fpn0, 5, x1, x2)], 4)
-        fpn1 = self.cba(nk.reduce_layer1, [f0], 4)
-        pan2 = self.stage(nk.Rep_p3, [self.bifusion(nk.Bifusion1, fpn1, 4, x2, x3)], 3)
-        pan1 = self.stage(nk.Rep_n3, [self.cba(nk.downsample2, [pan2], 3), fpn1], 4)
-        pan0 = self.stage(nk.Rep_n4, [self.cba(nk.downsample1, [pan1], 4), fpn0], 5)
-        self.neck_ids = [pan2, pan1, pan0]
-        if det.nl != 3:
-            raise NotImplementedError('P6 heads are outside the hot-path scope')
+        # feats[k] is at stride level k + 2; the backbones return P2 only with fuse_P2 (CSPBepBackbone_P6: always)
+        bifusion = hasattr(nk, 'Bifusion0')
+        has_p2 = bool(getattr(bb, 'fuse_P2', False)) or type(bb).__name__ == 'CSPBepBackbone_P6'
+        if bifusion and not has_p2:
+            raise NotImplementedError('the BiFusion necks need the P2 output of the backbone (fuse_P2=True)')
+        if not bifusion and has_p2:
+            raise ValueError('the plain PAN necks take (P3, P4, P5[, P6]): build the backbone with fuse_P2=False')
+        nlev = 4 if p6 else 3
+        if det.nl != nlev:
+            raise ValueError('head with %d levels on a neck with %d outputs' % (det.nl, nlev))
+        names_p = ['Rep_p5', 'Rep_p4', 'Rep_p3'] if p6 else ['Rep_p4', 'Rep_p3']
+        names_n = ['Rep_n4', 'Rep_n5', 'Rep_n6'] if p6 else ['Rep_n3', 'Rep_n4']
+        downs = ['downsample2', 'downsample1', 'downsample0'] if p6 else ['downsample2', 'downsample1']
+        x, sl = feats[-1], last                                    # top-down (reppan.py forward passes)
+        fpn = []
+        for k in range(nlev - 1):
+            f = self.cba(getattr(nk, 'reduce_layer%d' % k), [x], sl)
+            fpn.append(f)
+            if bifusion:
+                t = [self.bifusion(getattr(nk, 'Bifusion%d' % k), f, sl, feats[-2 - k], feats[-3 - k])]
+            else:                                                  # torch.cat([upsample(f), x_below]) read as two sources
+                t = [self.upsample(getattr(nk, 'upsample%d' % k), f, sl), feats[-2 - k]]
+            sl -= 1
+            x = self.stage(getattr(nk, names_p[k]), t, sl)
+        self.neck_ids = [x]
+        for k in range(nlev - 1):                                  # bottom-up
+            d = self.cba(getattr(nk, downs[k]), [x], sl)
+            sl += 1
+            x = self.stage(getattr(nk, names_n[k]), [d, fpn[-1 - k]], sl)
+            self.neck_ids.append(x)
         for i, f in enumerate(self.neck_ids):                     # effidehead.py:228-245
             sl = 3 + i
-            self.lane(i)                                  # level i: stem + class tower on lane i, box tower on the next lane
+            self.lane(i % 3)                              # level i: stem + class tower on one lane, box tower on the next
             s = self.cba(det.stems[i], [f], sl)
             c = self.cba(det.cls_convs[i], [s], sl)
             preds = [getattr(det, '%s_preds' % h)[i] for h in CLS_HEADS]
@@ -290,7 +318,8 @@ class Engine:
             raise ValueError('input height/width must be multiples of 32, got %dx%d' % (H, W))
         need = self.lib.lp_engine_arena_bytes(self.h, B, H, W)
         if need == 0:
-            raise ValueError('bad input shape %s' % ((B, H, W),))
+            raise ValueError('bad input shape %s: H and W must be positive multiples of the coarsest stride of the model '
+                             '(32; 64 with a P6 level)' % ((B, H, W),))
         if self.arena is None or self.arena.numel() < need + 256:
             self.arena = None
             self.arena = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)

@@ -31,8 +31,10 @@ def randomize(model, seed=1, sigma=0.35, bias_sigma=0.5):
     return model
 
 
-def build_synthetic(cfg_path, seed=0, rand_seed=1, sigma=0.35, width=None, npro=31, nalp=24, nads=37):
-    """Seeded model of a config file (optionally with another width multiple), randomised, eval mode."""
+def build_synthetic(cfg_path, seed=0, rand_seed=1, sigma=0.35, width=None, npro=31, nalp=24, nads=37, depth=None, neck=None,
+                    fuse_P2=None):
+    """Seeded model of a config file (optionally with another width / depth multiple, neck type or fuse_P2 flag),
+    randomised, eval mode."""
     from yolov6.utils.config import Config
     from yolov6.models.yolo import build_model
     cfg = Config.fromfile(cfg_path)
@@ -40,6 +42,12 @@ def build_synthetic(cfg_path, seed=0, rand_seed=1, sigma=0.35, width=None, npro=
         cfg.training_mode = 'repvgg'
     if width is not None:
         cfg.model.width_multiple = width
+    if depth is not None:
+        cfg.model.depth_multiple = depth
+    if neck is not None:
+        cfg.model.neck.type = neck
+    if fuse_P2 is not None:
+        cfg.model.backbone.fuse_P2 = fuse_P2
     torch.manual_seed(seed)
     model = build_model(cfg, npro, nalp, nads, 'cpu')
     return randomize(model, rand_seed, sigma).eval()
