@@ -359,3 +359,39 @@ def test_eval_counts_edges():
     with pytest.raises(ValueError):
         runtime.eval_counts(torch.zeros(2, 4, 28, device='cuda'), torch.zeros(2, dtype=torch.int32, device='cuda'),
                             torch.zeros(3, 1, 20, device='cuda'), torch.zeros(3, dtype=torch.int32, device='cuda'))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C,H,W,B', [(64, 128, 96, 2), (128, 96, 32, 3), (192, 64, 64, 1)])
+def test_head_cls_rows_variant(C, H, W, B, dtype):
+    """The row-writer form of the class predictors (cfg 7) against the tiled generic kernel: bit-identical columns
+    13..289, also when 32-anchor tiles straddle images (12x4 = 48 anchors per image) and at the ragged tail."""
+    from yolov6.hip import abi
+    from yolov6.hip.runtime import _f32
+    eng = _engine(dtype)
+    feats = [eng.tensor(C, 3 + i) for i in range(3)]
+    for i, f in enumerate(feats):
+        wc, bc = _rand((277, C), 30 + i, 0.3), _rand((277,), 40 + i, 1.0)
+        abi.check(eng.lib.lp_engine_add_head_cls(eng.h, f, i, 277, eng._ptr(_f32(wc)), eng._ptr(_f32(bc))))
+    eng.finish()
+    eng.bind(B, H, W)
+    eng.autotune = False
+    for i, f in enumerate(feats):
+        _fill(eng, f, _rand((B, C, H >> (3 + i), W >> (3 + i)), 70 + i))
+    base = _run(eng, B, H, W)[..., 13:].clone()
+    sz = torch.empty(0, dtype=dtype).element_size()
+    fits = C % (128 // sz) == 0 and C // (128 // sz) <= 3
+    for op in (1, 2, 3):
+        if fits:
+            eng.set_variant(op, 7, 1)
+        else:
+            with pytest.raises(RuntimeError):
+                eng.set_variant(op, 7, 1)
+    if not fits:
+        return
+    got = _run(eng, B, H, W)[..., 13:]
+    assert torch.equal(got, base)
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    for op in (1, 2, 3):                      # and back to the tiled kernel
+        eng.set_variant(op, 2, 1)
+    assert torch.equal(_run(eng, B, H, W)[..., 13:], base)

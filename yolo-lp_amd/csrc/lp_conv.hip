@@ -12,6 +12,10 @@ int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
 int conv_stream_launch_bf16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
 int conv_stream_launch_f32(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
 
+int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_rows_launch_bf16(const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_rows_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st);
+
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
     const int sz = (int)dtype_size(dtype);
     ConvShape s;
@@ -149,6 +153,27 @@ int conv_stream_launch(int dtype, int wc, const ConvArgs& a0, int cb_pack, hipSt
         case LP_F32: return conv_stream_launch_f32(wc, a, cb_pack, lds, st);
     }
     return fail(LP_ERR_ARG, "conv1x1 stream: dtype");
+}
+
+// Row-writer form of the class predictors (lp_head_rows.inc): whether the op fits, and the launch.
+bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c) {
+    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168;
+    return nchunks >= 1 && nchunks <= 3 && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) && out_c == LP_PRED_COLS - 13;
+}
+
+int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) {
+    const int nchunks = a.chunk_begin[a.nsrc];
+    if (!head_rows_fits(dtype, nchunks, cb_pack, a.out_c)) return fail(LP_ERR_ARG, "head rows: op does not fit");
+    const int kc = 128 / (int)dtype_size(dtype);
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].cs % kc != 0) return fail(LP_ERR_ARG, "head rows: source channels are not whole 128-byte chunks");
+    if (a.nphase != 1 || a.out_scale != 1 || a.Ho != a.H || a.Wo != a.W || !a.out) return fail(LP_ERR_ARG, "head rows: bad geometry");
+    switch (dtype) {
+        case LP_F16: return head_rows_launch_f16(a, cb_pack, st);
+        case LP_BF16: return head_rows_launch_bf16(a, cb_pack, st);
+        case LP_F32: return head_rows_launch_f32(a, cb_pack, st);
+    }
+    return fail(LP_ERR_ARG, "head rows: dtype");
 }
 
 }  // namespace lp

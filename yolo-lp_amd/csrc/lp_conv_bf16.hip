@@ -1,6 +1,7 @@
 // Instantiates the implicit-GEMM conv kernels (lp_conv_kernel.inc) for bf16 activations.
 #include "lp_conv_kernel.inc"
 #include "lp_conv1x1_stream.inc"
+#include "lp_head_rows.inc"
 
 namespace lp {
 int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
@@ -9,4 +10,5 @@ int conv_launch_bf16(int cfg, int mode, int ksize, int stride, int nbuf, const C
 int conv_stream_launch_bf16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st) {
     return stream_launch_dtype<bf16>(wc, a, cb_pack, lds, st);
 }
+int head_rows_launch_bf16(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_rows_launch_dtype<bf16>(a, cb_pack, st); }
 }  // namespace lp

@@ -48,6 +48,7 @@ struct Op {
     // filled by finalize
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
     int stream_wc = 0, stream_rd = 2;   // stream_wc != 0: the streaming 1x1 kernel (2 or 4 cout tiles per wave) runs this op
+    int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -57,7 +58,7 @@ struct Launch {
     ConvArgs a;
     long long pred_off = 0;
     int cfg = 0, mode = 0, ks = 1, st = 1, nbuf = 1;
-    int stream_wc = 0, stream_rd = 2, cb_pack = 0;
+    int stream_wc = 0, stream_rd = 2, cb_pack = 0, rows = 0;
     bool is_conv = false;
 };
 
@@ -94,7 +95,7 @@ struct lp_engine {
     int graph_x_dtype = -1;
     unsigned long long graph_epoch = 0, epoch = 1;   // epoch changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd}
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows}
 };
 
 #define LP_MAX_LANES 3
@@ -521,7 +522,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -590,6 +591,15 @@ static bool stream_fits(const lp_engine* e, const Op& op, int wc) {
     return conv_stream_lds(e->dtype, wc, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB) >= 0;
 }
 
+// Whether the row-writer kernel can run a class-predictor op.
+static bool rows_fits(const lp_engine* e, const Op& op) {
+    if (op.kind != OP_HEAD_CLS) return false;
+    const int kc = 128 / (int)dtype_size(e->dtype);
+    for (int i = 0; i < op.nsrc; ++i)
+        if (e->tensors[op.src[i]].cs % kc != 0) return false;
+    return head_rows_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
+}
+
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
     ++e->epoch;
@@ -655,6 +665,7 @@ static int prepare_op(lp_engine* e, size_t idx) {
     L.nbuf = op.nbuf;
     L.stream_wc = op.stream_wc;
     L.stream_rd = op.stream_rd;
+    L.rows = op.rows;
     L.cb_pack = s.CB;
     return LP_OK;
 }
@@ -676,6 +687,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
     ConvArgs a = L.a;
     a.out = pred + L.pred_off;
+    if (L.mode == MODE_PRED && L.rows) return head_rows_launch(dt, a, L.cb_pack, st);
     return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
 }
 
@@ -825,6 +837,30 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     LP_HIP_CHECK(hipEventCreate(&e1));
     for (size_t i = 0; i < e->ops.size(); ++i) {
         Op& op = e->ops[i];
+        if (e->launches[i].is_conv && op.kind == OP_HEAD_CLS && rows_fits(e, op) && !getenv("LP_NO_HEAD_ROWS")) {
+            // class predictors: tiled generic kernel or the row writer
+            float best = -1.f;
+            int best_rows = 0;
+            for (int rows = 0; rows <= 1; ++rows) {
+                op.rows = rows;
+                if (prepare_op(e, i) != LP_OK || run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;
+                float ms_min = -1.f;
+                for (int round = 0; round < 3; ++round) {
+                    LP_HIP_CHECK(hipEventRecord(e0, st));
+                    for (int r = 0; r < reps; ++r) run_op(e, i, x, x_dtype, pred, st);
+                    LP_HIP_CHECK(hipEventRecord(e1, st));
+                    LP_HIP_CHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    LP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+                }
+                if (best < 0.f || ms_min < best) { best = ms_min; best_rows = rows; }
+            }
+            op.rows = best_rows;
+            rc = prepare_op(e, i);
+            if (rc) return rc;
+            continue;
+        }
         if (!e->launches[i].is_conv || op.mode != MODE_ACT) continue;
         const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
         int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile, best_wc = 0, best_rd = 2;
@@ -887,7 +923,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -895,6 +931,14 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
 extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int nbuf) {
     if (!e || !e->finalized || op_idx < 0 || op_idx >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_set_op_variant: op index");
     Op& op = e->ops[op_idx];
+    if (op.kind == OP_HEAD_CLS) {        // cfg 7: row writer; the op's packing tile (2 = C) selects the tiled kernel again
+        if (cfg == 7 && !rows_fits(e, op)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the row-writer kernel does not fit this op");
+        if (cfg != 7 && cfg != op.cfg) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: head_cls takes cfg 7 or its packing tile");
+        op.rows = cfg == 7;
+        e->tuned.erase({e->B, e->H, e->W});
+        if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
@@ -919,7 +963,7 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;   // reported as cfg 5 / 6 (2 / 4 cout tiles per wave), nbuf = ring depth
-    if (cfg) *cfg = stream ? (e->ops[op].stream_wc == 2 ? 5 : 6) : e->ops[op].cfg;
+    if (cfg) *cfg = e->ops[op].rows ? 7 : stream ? (e->ops[op].stream_wc == 2 ? 5 : 6) : e->ops[op].cfg;
     if (nbuf) *nbuf = stream ? e->ops[op].stream_rd : e->ops[op].nbuf;
     return LP_OK;
 }

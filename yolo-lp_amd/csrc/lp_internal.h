@@ -83,6 +83,10 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, c
 int conv_stream_lds(int dtype, int wc, int nchunks, int cb_pack);
 int conv_stream_launch(int dtype, int wc, const ConvArgs& a, int cb_pack, hipStream_t st);
 
+// Row-writer form of the class predictors (lp_head_rows.inc).
+bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c);
+int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);
+
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
 int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
