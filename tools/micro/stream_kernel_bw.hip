@@ -35,6 +35,11 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hsrc.size(); ++i) hsrc[i] = (unsigned short)(0x3000 + (rand() & 0x3ff));   // random small f16 values
     CK(hipMemcpy(src, hsrc.data(), bytes, hipMemcpyHostToDevice));
     char* wts; CK(hipMalloc(&wts, 1 << 20)); CK(hipMemset(wts, 0, 1 << 20));
+    if (argc > 2 && atoi(argv[2])) {     // non-zero weights: outputs are not all zero
+        std::vector<unsigned short> hw(64 * 64);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = (unsigned short)(0x2c00 + (rand() & 0x3ff));
+        CK(hipMemcpy(wts + 4096, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
     lp::ConvArgs a; memset(&a, 0, sizeof(a));
     a.nsrc = 1; a.src[0].ptr = src; a.src[0].cs = C;
     for (int i = 1; i <= LP_MAX_SRC; ++i) a.chunk_begin[i] = 1;
