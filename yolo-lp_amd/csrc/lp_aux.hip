@@ -113,56 +113,100 @@ int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, in
 // group lives in LDS and each pool is a separable row pass + column pass (max is exact in every dtype, so
 // separability and the activation dtype do not change results).  Out-of-image taps are skipped, which is
 // what -inf padding does.
-template <typename T>
-__global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
-                                                        T* __restrict__ d3, int h, int w, int cs) {
-    typedef T V8 __attribute__((ext_vector_type(8)));          // the 8 channels of one pixel: 16 B (fp32: 32 B)
-    extern __shared__ __attribute__((aligned(16))) char pool_smem[];
-    const int hw = h * w;
-    V8* cur = (V8*)pool_smem;     // [hw]
-    V8* tmp = cur + hw;           // [hw]
-    const int groups = cs / 8;
-    const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
-    const long long base = (long long)b * hw * cs + cg * 8;
-    auto vmax = [](V8 a, V8 c) {
+// Element-wise max of 8 channels (one 16-B granule; fp32: 32 B).  fp16 uses the packed max (4 instructions, no
+// conversions); max of finite values is exact in every type.
+template <typename T> struct Max8 {
+    typedef T V8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ V8 f(V8 a, V8 c) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] = (float)c[k] > (float)a[k] ? c[k] : a[k];
         return a;
-    };
-    for (int p = threadIdx.x; p < hw; p += 256) cur[p] = *(const V8*)(src + base + (long long)p * cs);
+    }
+};
+template <> struct Max8<f16> {
+    typedef f16 V8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ V8 f(V8 a, V8 c) { return __builtin_elementwise_max(a, c); }
+};
+
+// One workgroup per (image, GP granules = 8*GP channels): the plane sits in LDS, three chained separable 5x5 passes.
+// A work item is (pixel, granule), so neighbouring lanes move neighbouring 16-B pieces of a pixel's channel run.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
+                                                        T* __restrict__ d3, int h, int w, int cs, int gp_log2, unsigned w_magic) {
+    typedef T V8 __attribute__((ext_vector_type(8)));          // the 8 channels of one granule: 16 B (fp32: 32 B)
+    extern __shared__ __attribute__((aligned(16))) char pool_smem[];
+    const int GP = 1 << gp_log2;
+    const int hw = h * w, items = hw * GP;
+    // p / w as a multiply-high (w_magic = floor(2^32 / w) + 1, exact for p < 2^16): an integer division per work item and
+    // pass was most of this kernel's instruction count
+    // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the round's global
+    // stores, three store round trips per workgroup that nothing depends on
+    auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto row_of = [&](int p) { return (int)__umulhi((unsigned)p, w_magic); };
+    V8* cur = (V8*)pool_smem;     // [hw][GP]
+    V8* tmp = cur + items;        // [hw][GP]
+    const int groups = cs / (8 * GP);
+    const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
+    const long long base = (long long)b * hw * cs + cg * 8 * GP;
+    for (int i0 = threadIdx.x; i0 < items; i0 += 256 * 8) {      // eight loads in flight per thread, then the LDS writes
+        V8 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256;
+            const int ic = i < items ? i : items - 1;
+            const int p = ic >> gp_log2, g = ic & (GP - 1);
+            v[k] = *(const V8*)(src + base + (long long)p * cs + g * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k * 256 < items) cur[i0 + k * 256] = v[k];
+    }
     __syncthreads();
-    T* outs[3] = {d1, d2, d3};
     for (int round = 0; round < 3; ++round) {
-        for (int p = threadIdx.x; p < hw; p += 256) {              // row pass
-            const int y = p / w, x = p - y * w;
+        T* const out = round == 0 ? d1 : round == 1 ? d2 : d3;      // (an indexed pointer array would live in scratch memory)
+        for (int i = threadIdx.x; i < items; i += 256) {           // row pass
+            const int p = i >> gp_log2, g = i & (GP - 1);
+            const int y = row_of(p), x = p - y * w;
             const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= w ? w - 1 : x + 2;
-            V8 m = cur[y * w + x0];
-            for (int xx = x0 + 1; xx <= x1; ++xx) m = vmax(m, cur[y * w + xx]);
-            tmp[p] = m;
+            V8 m = cur[(y * w + x0) * GP + g];
+            for (int xx = x0 + 1; xx <= x1; ++xx) m = Max8<T>::f(m, cur[(y * w + xx) * GP + g]);
+            tmp[i] = m;
         }
-        __syncthreads();
-        for (int p = threadIdx.x; p < hw; p += 256) {              // column pass
-            const int y = p / w, x = p - y * w;
+        lds_barrier();
+        for (int i = threadIdx.x; i < items; i += 256) {           // column pass
+            const int p = i >> gp_log2, g = i & (GP - 1);
+            const int y = row_of(p), x = p - y * w;
             const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= h ? h - 1 : y + 2;
-            V8 m = tmp[y0 * w + x];
-            for (int yy = y0 + 1; yy <= y1; ++yy) m = vmax(m, tmp[yy * w + x]);
-            *(V8*)(outs[round] + base + (long long)p * cs) = m;
-            cur[p] = m;   // only read again after the barrier below
+            V8 m = tmp[(y0 * w + x) * GP + g];
+            for (int yy = y0 + 1; yy <= y1; ++yy) m = Max8<T>::f(m, tmp[(yy * w + x) * GP + g]);
+            *(V8*)(out + base + (long long)p * cs + g * 8) = m;
+            cur[i] = m;   // only read again after the barrier below
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
 template <typename T>
 static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, int h, int w, int cs, hipStream_t st) {
-    const size_t lds = (size_t)h * w * 8 * sizeof(T) * 2;
-    if (lds > 128 * 1024) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
+    // granules per workgroup: the widest channel run (up to 64 channels = one 128-B line in 16-bit types) that still
+    // gives every CU two workgroups and fits the LDS (256 ch, 20x20, batch 32: 26 / 21 / 26 / 41 us for 1 / 2 / 4 / 8)
+    int gp = 1;
+    for (int cand = 8; cand >= 1; cand >>= 1) {
+        const size_t need = (size_t)h * w * cand * 8 * sizeof(T) * 2;
+        if ((cs / 8) % cand == 0 && need <= 64 * 1024 && (long long)B * (cs / 8 / cand) >= 512) { gp = cand; break; }
+    }
+    if (getenv("LP_POOL_GP")) gp = atoi(getenv("LP_POOL_GP"));   // experiments
+    const size_t lds = (size_t)h * w * gp * 8 * sizeof(T) * 2;
+    if (lds > 128 * 1024 || h * w >= 65536) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
+    int gp_log2 = 0;
+    while ((1 << gp_log2) < gp) ++gp_log2;
+    const unsigned w_magic = (unsigned)(0x100000000ULL / (unsigned)w) + 1u;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)pool_chain_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool attr: ") + hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((pool_chain_kernel<T>), dim3((unsigned)(B * (cs / 8))), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2,
-                       (T*)d3, h, w, cs);
+    hipLaunchKernelGGL((pool_chain_kernel<T>), dim3((unsigned)(B * (cs / 8 / gp))), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2,
+                       (T*)d3, h, w, cs, gp_log2, w_magic);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool launch: ") + hipGetErrorString(e));
     return LP_OK;
