@@ -197,7 +197,7 @@ def test_deconv2x2(cin, cout, h, w, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('c,h,w', [(256, 20, 20), (64, 13, 7), (8, 4, 3), (40, 40, 40)])
+@pytest.mark.parametrize('c,h,w', [(256, 20, 20), (64, 13, 7), (8, 4, 3), (40, 40, 40), (32, 2, 1), (16, 1, 5)])
 def test_pool_chain(c, h, w, dtype):
     from yolov6.hip import abi
     eng = _engine(dtype)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ s
     // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for the round's global
     // stores, three store round trips per workgroup that nothing depends on
     auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto row_of = [&](int p) { return (int)__umulhi((unsigned)p, w_magic); };
+    auto row_of = [&](int p) { return w == 1 ? p : (int)__umulhi((unsigned)p, w_magic); };   // (2^32 / 1 does not fit the magic)
     V8* cur = (V8*)pool_smem;     // [hw][GP]
     V8* tmp = cur + items;        // [hw][GP]
     const int groups = cs / (8 * GP);
