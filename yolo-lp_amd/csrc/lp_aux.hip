@@ -195,7 +195,6 @@ static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, i
         const size_t need = (size_t)h * w * cand * 8 * sizeof(T) * 2;
         if ((cs / 8) % cand == 0 && need <= 64 * 1024 && (long long)B * (cs / 8 / cand) >= 512) { gp = cand; break; }
     }
-    if (getenv("LP_POOL_GP")) gp = atoi(getenv("LP_POOL_GP"));   // experiments
     const size_t lds = (size_t)h * w * gp * 8 * sizeof(T) * 2;
     if (lds > 128 * 1024 || h * w >= 65536) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
     int gp_log2 = 0;
