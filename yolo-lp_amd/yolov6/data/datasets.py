@@ -1,9 +1,10 @@
-"""``LoadData``: image file / directory iterator of the inference path (host-side
-mirror of reference yolov6/data/datasets.py:745-795).  Frames are BGR uint8 HWC
-arrays like ``cv2.imread`` returns; PIL is used when OpenCV is absent.  Video
-sources need OpenCV.  The training dataset classes are out of scope."""
-import glob
-import os
+"""``LoadData``: the frame source of the inference path -- one image file, or every image / video under a directory
+(host-side counterpart of reference yolov6/data/datasets.py:745-795; the training dataset classes are out of scope).
+
+Iterating yields ``(frame, path, capture)``: ``frame`` is a BGR uint8 HWC array as ``cv2.imread`` returns it (PIL is
+used when OpenCV is absent), ``capture`` is the open ``cv2.VideoCapture`` while a video is being read and ``None`` for
+images; ``.type`` says which kind the last frame came from, ``len()`` is the number of source files.
+"""
 from pathlib import Path
 
 import numpy as np
@@ -25,58 +26,52 @@ def imread_bgr(path):
         return np.ascontiguousarray(np.asarray(im.convert('RGB'))[:, :, ::-1])
 
 
+def _suffix(path):
+    return path.rsplit('.', 1)[-1]
+
+
 class LoadData:
     def __init__(self, path):
-        p = str(Path(path).resolve())
-        if os.path.isdir(p):
-            files = sorted(glob.glob(os.path.join(p, '**/*.*'), recursive=True))
-        elif os.path.isfile(p):
-            files = [p]
+        root = Path(path).resolve()
+        if root.is_dir():
+            found = sorted(str(f) for f in root.rglob('*.*'))
+        elif root.is_file():
+            found = [str(root)]
         else:
-            raise FileNotFoundError(f'Invalid path {p}')
-        imgp = [i for i in files if i.split('.')[-1] in IMG_FORMATS]
-        vidp = [v for v in files if v.split('.')[-1] in VID_FORMATS]
-        self.files = imgp + vidp
+            raise FileNotFoundError(f'Invalid path {root}')
+        # images first, then videos (the reference's order); the image test is case-sensitive at listing time there too
+        self.files = [f for f in found if _suffix(f) in IMG_FORMATS] + [f for f in found if _suffix(f) in VID_FORMATS]
         self.nf = len(self.files)
         self.type = 'image'
         self.cap = None
-        if any(vidp):
-            self.add_video(vidp[0])
 
     @staticmethod
     def checkext(path):
-        return 'image' if path.split('.')[-1].lower() in IMG_FORMATS else 'video'
+        return 'image' if _suffix(path).lower() in IMG_FORMATS else 'video'
 
-    def __iter__(self):
-        self.count = 0
-        return self
-
-    def __next__(self):
-        if self.count == self.nf:
-            raise StopIteration
-        path = self.files[self.count]
-        if self.checkext(path) == 'video':
-            self.type = 'video'
-            ret_val, img = self.cap.read()
-            while not ret_val:
-                self.count += 1
-                self.cap.release()
-                if self.count == self.nf:
-                    raise StopIteration
-                path = self.files[self.count]
-                self.add_video(path)
-                ret_val, img = self.cap.read()
-        else:
-            self.count += 1
-            img = imread_bgr(path)
-        return img, path, self.cap
-
-    def add_video(self, path):
+    def _frames_of(self, path):
         if cv2 is None:
             raise RuntimeError('video sources need OpenCV, which is not installed')
-        self.frame = 0
         self.cap = cv2.VideoCapture(path)
         self.frames = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        try:
+            while True:
+                ok, frame = self.cap.read()
+                if not ok:
+                    return
+                yield frame
+        finally:
+            self.cap.release()
+
+    def __iter__(self):
+        for path in self.files:
+            if self.checkext(path) == 'image':
+                self.type, self.cap = 'image', None
+                yield imread_bgr(path), path, None
+            else:
+                self.type = 'video'
+                for frame in self._frames_of(path):
+                    yield frame, path, self.cap
 
     def __len__(self):
         return self.nf
