@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Inference entry point (same flags and ``run`` signature as reference tools/infer.py:19-107).
+"""Inference entry point: the flags and the ``run`` keyword arguments of reference tools/infer.py:19-107.
 
     python tools/infer.py --weights weights/yololps.pt --source data/images --yaml data/dataset.yaml [--half]
 """
@@ -17,29 +17,35 @@ if str(ROOT) not in sys.path:
 from yolov6.utils.events import LOGGER      # noqa: E402
 from yolov6.core.inferer import Inferer      # noqa: E402
 
+# (flag, argparse keywords): the reference's flag set, defaults included
+_FLAGS = [
+    ('--weights', dict(type=str, default='weights/yolov6s.pt', help='checkpoint (.pt) to run')),
+    ('--source', dict(type=str, default='data/images', help='image file or directory of images / videos')),
+    ('--yaml', dict(type=str, default='data/dataset.yaml', help='dataset yaml (class names)')),
+    ('--img-size', dict(nargs='+', type=int, default=[640, 640], help='network input size, h w')),
+    ('--conf-thres', dict(type=float, default=0.4, help='score threshold of the NMS')),
+    ('--iou-thres', dict(type=float, default=0.45, help='IoU threshold of the NMS')),
+    ('--max-det', dict(type=int, default=1000, help='detections kept per image')),
+    ('--device', dict(default='0', help='GPU index (0, or 0,1,2,3) or cpu')),
+    ('--save-txt', dict(action='store_true', help='write one label file per image')),
+    ('--not-save-img', dict(action='store_true', help='do not write the annotated images')),
+    ('--save-dir', dict(type=str, help='output directory (default: project/name)')),
+    ('--view-img', dict(action='store_true', help='show the annotated frames')),
+    ('--classes', dict(nargs='+', type=int, help='keep these class ids only')),
+    ('--agnostic-nms', dict(action='store_true', help='class-agnostic NMS')),
+    ('--project', dict(default='runs/inference', help='parent of the default output directory')),
+    ('--name', dict(default='exp', help='name of the default output directory')),
+    ('--hide-labels', dict(default=False, action='store_true', help='draw boxes without text')),
+    ('--hide-conf', dict(default=False, action='store_true', help='draw labels without scores')),
+    ('--half', dict(action='store_true', help='fp16 engine')),
+]
+
 
 def get_args_parser(add_help=True):
-    p = argparse.ArgumentParser(description='YOLO-LP inference on MI355X (HIP engine) or CPU.', add_help=add_help)
-    p.add_argument('--weights', type=str, default='weights/yolov6s.pt', help='model path(s) for inference.')
-    p.add_argument('--source', type=str, default='data/images', help='the source path, e.g. image-file/dir.')
-    p.add_argument('--yaml', type=str, default='data/dataset.yaml', help='data yaml file.')
-    p.add_argument('--img-size', nargs='+', type=int, default=[640, 640], help='the image-size(h,w) in inference size.')
-    p.add_argument('--conf-thres', type=float, default=0.4, help='confidence threshold for inference.')
-    p.add_argument('--iou-thres', type=float, default=0.45, help='NMS IoU threshold for inference.')
-    p.add_argument('--max-det', type=int, default=1000, help='maximal inferences per image.')
-    p.add_argument('--device', default='0', help='device to run our model i.e. 0 or 0,1,2,3 or cpu.')
-    p.add_argument('--save-txt', action='store_true', help='save results to *.txt.')
-    p.add_argument('--not-save-img', action='store_true', help='do not save visuallized inference results.')
-    p.add_argument('--save-dir', type=str, help='directory to save predictions in. See --save-txt.')
-    p.add_argument('--view-img', action='store_true', help='show inference results')
-    p.add_argument('--classes', nargs='+', type=int, help='filter by classes, e.g. --classes 0, or --classes 0 2 3.')
-    p.add_argument('--agnostic-nms', action='store_true', help='class-agnostic NMS.')
-    p.add_argument('--project', default='runs/inference', help='save inference results to project/name.')
-    p.add_argument('--name', default='exp', help='save inference results to project/name.')
-    p.add_argument('--hide-labels', default=False, action='store_true', help='hide labels.')
-    p.add_argument('--hide-conf', default=False, action='store_true', help='hide confidences.')
-    p.add_argument('--half', action='store_true', help='whether to use FP16 half-precision inference.')
-    args = p.parse_args()
+    parser = argparse.ArgumentParser(description='YOLO-LP inference on MI355X (HIP engine) or CPU.', add_help=add_help)
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **kw)
+    args = parser.parse_args()
     LOGGER.info(args)
     return args
 
@@ -49,19 +55,18 @@ def run(weights=osp.join(ROOT, 'yolov6s.pt'), source=osp.join(ROOT, 'data/images
         conf_thres=0.4, iou_thres=0.45, max_det=1000, device='', save_txt=False, not_save_img=False, save_dir=None,
         view_img=True, classes=None, agnostic_nms=False, project=osp.join(ROOT, 'runs/inference'), name='exp',
         hide_labels=False, hide_conf=False, half=False):
-    if save_dir is None:
-        save_dir = osp.join(project, name)
-    if (not not_save_img or save_txt) and not osp.exists(save_dir):
-        os.makedirs(save_dir)
+    save_img = not not_save_img
+    out_dir = save_dir if save_dir is not None else osp.join(project, name)
+    if (save_img or save_txt) and not osp.exists(out_dir):
+        os.makedirs(out_dir)
     else:
         LOGGER.warning('Save directory already existed')
     if save_txt:
-        os.makedirs(osp.join(save_dir, 'labels'), exist_ok=True)
-    inferer = Inferer(source, weights, device, yaml, img_size, half)
-    results = inferer.infer(conf_thres, iou_thres, classes, agnostic_nms, max_det, save_dir, save_txt, not not_save_img,
-                            hide_labels, hide_conf, view_img)
-    if save_txt or not not_save_img:
-        LOGGER.info(f"Results saved to {save_dir}")
+        os.makedirs(osp.join(out_dir, 'labels'), exist_ok=True)
+    results = Inferer(source, weights, device, yaml, img_size, half).infer(
+        conf_thres, iou_thres, classes, agnostic_nms, max_det, out_dir, save_txt, save_img, hide_labels, hide_conf, view_img)
+    if save_txt or save_img:
+        LOGGER.info(f"Results saved to {out_dir}")
     return results
 
 

@@ -28,16 +28,18 @@ def initialize_weights(model):
 
 
 def fuse_conv_and_bn(conv, bn):
-    """Fold an eval-mode BN into the preceding conv (reference :50-82):
-    ``W' = diag(gamma/sqrt(eps+var)) W``, ``b' = W_bn b + beta - gamma*mu/sqrt(var+eps)``."""
+    """Eval-mode BN folded into the conv in front of it (reference :50-82): with ``s = gamma / sqrt(var + eps)`` per output
+    channel, ``W' = s * W`` and ``b' = s * b + beta - s * mu``.  The reference writes the scaling as products with
+    ``diag(s)``; a diagonal matrix product adds exact zeros to one term per element, so the row scaling below gives the
+    same bits."""
+    dev = conv.weight.device
+    s = bn.weight.div(torch.sqrt(bn.eps + bn.running_var))
     fused = nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=conv.kernel_size, stride=conv.stride,
-                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False).to(conv.weight.device)
-    w_conv = conv.weight.clone().view(conv.out_channels, -1)
-    w_bn = torch.diag(bn.weight.div(torch.sqrt(bn.eps + bn.running_var)))
-    fused.weight.copy_(torch.mm(w_bn, w_conv).view(fused.weight.shape))
-    b_conv = torch.zeros(conv.weight.size(0), device=conv.weight.device) if conv.bias is None else conv.bias
-    b_bn = bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))
-    fused.bias.copy_(torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn)
+                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False).to(dev)
+    fused.weight.copy_((conv.weight.clone().view(conv.out_channels, -1) * s[:, None]).view(fused.weight.shape))
+    b = conv.bias if conv.bias is not None else torch.zeros(conv.out_channels, device=dev)
+    shift = bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))
+    fused.bias.copy_(b * s + shift)
     return fused
 
 
