@@ -281,6 +281,58 @@ def test_infer_entry_point_on_gpu(tmp_path, monkeypatch):
     assert half.shape[1] == 28
 
 
+def test_eval_entry_point_val_on_gpu(tmp_path, monkeypatch):
+    """tools/eval.py::run --task val on the GPU: labels beside the images, Evaler.predict / eval with the metric counters
+    from lp_eval_counts; the counters must equal the oracle's on the very detections the run produced."""
+    import sys
+    import importlib
+    import numpy as np
+    from PIL import Image
+    from oracle import lp_metric as M
+    from yolov6.utils import lp_metric
+    from yolov6.utils.synth import build_synthetic
+    monkeypatch.chdir(REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    ev = importlib.import_module('eval')
+    m = build_synthetic(CFG('yololps'), width=0.0625, sigma=1.5)
+    ckpt = tmp_path / 'tiny.pt'
+    torch.save({'model': m.half(), 'ema': None}, str(ckpt))
+    img_dir, lab_dir = tmp_path / 'ds' / 'images' / 'val', tmp_path / 'ds' / 'labels' / 'val'
+    img_dir.mkdir(parents=True)
+    lab_dir.mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 255, (240, 320, 3), dtype=np.uint8)).save(str(img_dir / ('f%d.png' % i)))
+    kw = dict(weights=str(ckpt), batch_size=2, img_size=128, conf_thres=0.03, iou_thres=0.65, task='val', half=False,
+              name='exp')
+    # first pass without labels: take some detections of the GPU run as labels (so that matches exist), second pass scores them
+    preds, _, metrics = ev.run(str(img_dir), device='0', save_dir=str(tmp_path / 'v0'), **kw)
+    assert metrics is None
+    dets = [d for b in preds for d in b]
+    assert sum(len(d) for d in dets) > 0
+    for i, d in enumerate(dets):
+        rows = []
+        for det in d[:2].cpu().tolist():
+            x1, y1, x2, y2 = det[:4]
+            # invert the letterbox of a 240x320 frame in a 128x128 input: ratio 0.4, top pad 16
+            box = [((x1 + x2) / 2) / 0.4 / 320, (((y1 + y2) / 2) - 16) / 0.4 / 240, (x2 - x1) / 0.4 / 320, (y2 - y1) / 0.4 / 240]
+            cor = [(v / 0.4 / 320) if k % 2 == 0 else ((v - 16) / 0.4 / 240) for k, v in enumerate(det[4:12])]
+            rows.append(' '.join('%.6f' % v for v in det[20:28] + box + cor))
+        if rows:
+            (lab_dir / ('f%d.txt' % i)).write_text('\n'.join(rows) + '\n')
+    preds, _, metrics = ev.run(str(img_dir), device='0', save_dir=str(tmp_path / 'v1'), **kw)
+    assert metrics is not None and len(metrics) == 7
+    targets = [b[1] for b in ev.image_batches(str(img_dir), 128, 2)]
+    from yolov6.core.evaler import Evaler
+    val = Evaler(None, device=torch.device('cuda:0'), half=False)
+    split = [val.split_targets(t, 2 if k < 2 else 1, 128, 128) for k, t in enumerate(targets)]
+    ref_c = M.counts([[p.cpu().numpy() for p in b] for b in preds], [[t.cpu().numpy() for t in b] for b in split], strict=False)
+    got_c = lp_metric.counts(preds, split)
+    assert got_c.tolist() == ref_c.tolist()
+    assert int(ref_c[M.I_TRUE]) > 0 and int(ref_c[M.I_PRED_BINS:M.I_PRED_BINS + 10].sum()) > 0
+    assert metrics == lp_metric.finish(got_c)
+
+
 def test_gather_detections_rccl_on_side_stream():
     """The all-gather of padded detections through RCCL (backend nccl), issued on a side stream like bench.py does;
     one rank is all a one-GPU box offers, so this checks the plumbing (RCCL loads, the collective runs on our tensors
