@@ -832,9 +832,13 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     hipStream_t st = (hipStream_t)stream;
     rc = forward_single_lane(e, x, x_dtype, pred, st);
     if (rc) return rc;
-    hipEvent_t e0, e1;
-    LP_HIP_CHECK(hipEventCreate(&e0));
-    LP_HIP_CHECK(hipEventCreate(&e1));
+    struct EventPair {      // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evp;
+    LP_HIP_CHECK(hipEventCreate(&evp.a));
+    LP_HIP_CHECK(hipEventCreate(&evp.b));
+    const hipEvent_t e0 = evp.a, e1 = evp.b;
     for (size_t i = 0; i < e->ops.size(); ++i) {
         Op& op = e->ops[i];
         if (e->launches[i].is_conv && op.kind == OP_HEAD_CLS && rows_fits(e, op) && !getenv("LP_NO_HEAD_ROWS")) {
@@ -920,8 +924,6 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         rc = prepare_op(e, i);
         if (rc) return rc;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     std::vector<std::vector<int>> choice;
     for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows});
     e->tuned[{e->B, e->H, e->W}] = choice;
