@@ -395,3 +395,50 @@ def test_head_cls_rows_variant(C, H, W, B, dtype):
     for op in (1, 2, 3):                      # and back to the tiled kernel
         eng.set_variant(op, 2, 1)
     assert torch.equal(_run(eng, B, H, W)[..., 13:], base)
+
+
+VARIANT_SHAPES = [
+    # (cin list, cout, k, s, map size): every packing class, both strides, single / multi source, a small-M case
+    ([64], 64, 3, 1, 80), ([64], 128, 3, 2, 80), ([128], 128, 3, 1, 40), ([128], 256, 3, 2, 40), ([256], 256, 3, 1, 20),
+    ([64], 64, 1, 1, 80), ([128, 64], 64, 1, 1, 80), ([256], 128, 1, 1, 40), ([128, 128, 128], 128, 1, 1, 40),
+]
+
+
+@pytest.mark.parametrize('act', ['relu', 'silu'])
+@pytest.mark.parametrize('shape', VARIANT_SHAPES, ids=lambda c: '%s-%d-k%ds%d-%d' % ('+'.join(map(str, c[0])), c[1], c[2], c[3], c[4]))
+def test_every_kernel_variant_gives_the_same_bits(shape, act):
+    """The autotuner may pick any variant (workgroup tile, ring depth, streaming kernel) per layer and per input shape, so
+    all of them must agree bit for bit -- otherwise results would depend on timing noise and on the batch size.  (SiLU once
+    differed by one fp16 ulp between instantiations: the compiler folded its multiply into the f32 -> f16 conversion in
+    some of them.)"""
+    from yolov6.hip import abi
+    cins, cout, k, s, hw = shape
+    B, sl, dtype = 2, 5, torch.float16
+    eng = _engine(dtype)
+    eng.autotune = False
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, k, k), 1, (2.0 / (cin * k * k)) ** 0.5)
+    act_id = {'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, _rand((cout,), 2, 0.3), k, s, act_id, sl)
+    eng.finish()
+    eng.bind(B, hw << sl, hw << sl)
+    for i, (t, c) in enumerate(zip(srcs, cins)):
+        _fill(eng, t, _rand((B, c, hw, hw), 10 + i))
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    base, tried = None, 0
+    for cfg in range(7):
+        for nb in (1, 2):
+            try:
+                eng.set_variant(op, cfg, nb)
+            except RuntimeError:
+                continue
+            eng.tensor_view(dst).zero_()
+            _run(eng, B, hw << sl, hw << sl)
+            out = eng.tensor_view(dst).clone()
+            tried += 1
+            if base is None:
+                base = out
+            else:
+                assert torch.equal(out, base), (cfg, nb)
+    assert tried >= 2
