@@ -401,6 +401,7 @@ VARIANT_SHAPES = [
     # (cin list, cout, k, s, map size): every packing class, both strides, single / multi source, a small-M case
     ([64], 64, 3, 1, 80), ([64], 128, 3, 2, 80), ([128], 128, 3, 1, 40), ([128], 256, 3, 2, 40), ([256], 256, 3, 1, 20),
     ([64], 64, 1, 1, 80), ([128, 64], 64, 1, 1, 80), ([256], 128, 1, 1, 40), ([128, 128, 128], 128, 1, 1, 40),
+    ([64], 64, 3, 1, 40, 'res'), ([128], 128, 3, 1, 20, 'res'), ([128], 128, 1, 1, 40, 'res'),      # BottleRep residual epilogue
 ]
 
 
@@ -412,7 +413,8 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act):
     differed by one fp16 ulp between instantiations: the compiler folded its multiply into the f32 -> f16 conversion in
     some of them.)"""
     from yolov6.hip import abi
-    cins, cout, k, s, hw = shape
+    cins, cout, k, s, hw = shape[:5]
+    use_res = len(shape) > 5
     B, sl, dtype = 2, 5, torch.float16
     eng = _engine(dtype)
     eng.autotune = False
@@ -420,11 +422,14 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act):
     cin = sum(cins)
     wt = _rand((cout, cin, k, k), 1, (2.0 / (cin * k * k)) ** 0.5)
     act_id = {'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
-    dst = eng.conv(srcs, wt, _rand((cout,), 2, 0.3), k, s, act_id, sl)
+    res_id = eng.tensor(cout, sl) if use_res else None
+    dst = eng.conv(srcs, wt, _rand((cout,), 2, 0.3), k, s, act_id, sl, res=res_id, alpha=0.7)
     eng.finish()
     eng.bind(B, hw << sl, hw << sl)
     for i, (t, c) in enumerate(zip(srcs, cins)):
         _fill(eng, t, _rand((B, c, hw, hw), 10 + i))
+    if use_res:
+        _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     base, tried = None, 0
     for cfg in range(7):
