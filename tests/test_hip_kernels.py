@@ -405,9 +405,10 @@ VARIANT_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
 @pytest.mark.parametrize('act', ['relu', 'silu'])
 @pytest.mark.parametrize('shape', VARIANT_SHAPES, ids=lambda c: '%s-%d-k%ds%d-%d' % ('+'.join(map(str, c[0])), c[1], c[2], c[3], c[4]))
-def test_every_kernel_variant_gives_the_same_bits(shape, act):
+def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
     """The autotuner may pick any variant (workgroup tile, ring depth, streaming kernel) per layer and per input shape, so
     all of them must agree bit for bit -- otherwise results would depend on timing noise and on the batch size.  (SiLU once
     differed by one fp16 ulp between instantiations: the compiler folded its multiply into the f32 -> f16 conversion in
@@ -415,7 +416,7 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act):
     from yolov6.hip import abi
     cins, cout, k, s, hw = shape[:5]
     use_res = len(shape) > 5
-    B, sl, dtype = 2, 5, torch.float16
+    B, sl = 2, 5
     eng = _engine(dtype)
     eng.autotune = False
     srcs = [eng.tensor(c, sl) for c in cins]
