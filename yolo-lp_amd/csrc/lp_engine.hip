@@ -390,10 +390,10 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
             op.cfg = pick_cfg(dt, ks, st, cout_store);
             // default variant of the 128-cout class; lp_engine_autotune() picks per layer among the variants that
             // share this packing.  LP_TUNE_CFG128 / LP_TUNE_NBUF force one for experiments.
-            if (op.cfg == CFG_A) op.cfg = CFG_E;
+            if (op.cfg == CFG_A) op.cfg = CFG_D;
             const char* tc = getenv("LP_TUNE_CFG128");
             const char* tb = getenv("LP_TUNE_NBUF");
-            if (tc && op.cfg == CFG_E) op.cfg = atoi(tc);
+            if (tc && op.cfg == CFG_D) op.cfg = atoi(tc);
             if (tb && op.cfg != CFG_C) op.nbuf = atoi(tb) == 2 ? 2 : 1;
         }
         const ConvShape s = conv_shape(dt, op.cfg, ks, st);
