@@ -139,10 +139,11 @@ int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, voi
  * that share the op's weight packing, by timing each in place (hipEvent pairs on `stream`).  The choice is
  * remembered per (B,H,W) and re-applied by lp_engine_bind.  Variants differ only in tiling: every output element
  * is the same fp32 sum in the same K order, so results do not depend on the choice.  lp_engine_op_variant reports
- * the current choice of an op (cfg: 0..4 = workgroup tile A..E of the implicit-GEMM kernel, nbuf: LDS ring depth 1 or
- * 2; cfg 5 / 6 = the streaming 1x1 kernel with 64 / 128 output channels per wave, nbuf: always 2; cfg 7 = the row-writer
- * form of a head_cls op).
+ * the current choice of an op: cfg = a workgroup tile of the implicit-GEMM kernel (0..5 = A..F) with
+ * nbuf = LDS ring depth 1 or 2, or LP_VARIANT_STREAM64 / LP_VARIANT_STREAM128 (streaming 1x1 kernel with 64 / 128 output
+ * channels per wave, nbuf 2), or LP_VARIANT_ROWS (row-writer form of a head_cls op, nbuf 1).
  * lp_engine_set_op_variant forces one (tests, experiments): LP_ERR_UNSUPPORTED if it does not fit the op. */
+enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18 };
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);

@@ -101,7 +101,7 @@ STREAM_CASES = [
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('variant', [(5, 2), (6, 2)], ids=lambda v: 'wc%d' % (2 if v[0] == 5 else 4))
+@pytest.mark.parametrize('variant', [(16, 2), (17, 2)], ids=lambda v: 'wc%d' % (2 if v[0] == 16 else 4))    # LP_VARIANT_STREAM64 / 128
 @pytest.mark.parametrize('case', STREAM_CASES, ids=lambda c: '%s-%d-%s%s' % ('+'.join(map(str, c[0])), c[1], c[2], '-res' if c[3] else ''))
 def test_conv1x1_stream(case, variant, dtype):
     """The streaming 1x1 kernel against the oracle, and bit-for-bit against the implicit-GEMM kernel on the same packing."""
@@ -135,7 +135,7 @@ def test_conv1x1_stream(case, variant, dtype):
     # padding: 128-row tiles only for multiples of 128), every source is made of whole 128-byte K-chunks, and the
     # resident weights + bias + staging fit the 160 KiB of LDS
     sz = torch.empty(0, dtype=dtype).element_size()
-    wc = 2 if variant[0] == 5 else 4
+    wc = 2 if variant[0] == 16 else 4
     kc = 128 // sz
     stored = [(c + 7) // 8 * 8 for c in cins]
     nchunks = sum(-(-c // kc) for c in stored)
@@ -168,7 +168,7 @@ def test_conv1x1_stream_rejects_unfit_ops():
     n = eng.lib.lp_engine_num_ops(eng.h)
     for op in (n - 2, n - 1):
         with pytest.raises(RuntimeError):
-            eng.set_variant(op, 5, 2)
+            eng.set_variant(op, 16, 2)
     with pytest.raises(RuntimeError):
         eng.set_variant(0, 0, 1)                          # the input op has no variants
 
@@ -364,7 +364,7 @@ def test_eval_counts_edges():
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('C,H,W,B', [(64, 128, 96, 2), (128, 96, 32, 3), (192, 64, 64, 1)])
 def test_head_cls_rows_variant(C, H, W, B, dtype):
-    """The row-writer form of the class predictors (cfg 7) against the tiled generic kernel: bit-identical columns
+    """The row-writer form of the class predictors (LP_VARIANT_ROWS) against the tiled generic kernel: bit-identical columns
     13..289, also when 32-anchor tiles straddle images (12x4 = 48 anchors per image) and at the ragged tail."""
     from yolov6.hip import abi
     from yolov6.hip.runtime import _f32
@@ -383,10 +383,10 @@ def test_head_cls_rows_variant(C, H, W, B, dtype):
     fits = C % (128 // sz) == 0 and C // (128 // sz) <= 3
     for op in (1, 2, 3):
         if fits:
-            eng.set_variant(op, 7, 1)
+            eng.set_variant(op, 18, 1)
         else:
             with pytest.raises(RuntimeError):
-                eng.set_variant(op, 7, 1)
+                eng.set_variant(op, 18, 1)
     if not fits:
         return
     got = _run(eng, B, H, W)[..., 13:]
@@ -433,7 +433,7 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     base, tried = None, 0
-    for cfg in range(7):
+    for cfg in list(range(8)) + [16, 17]:
         for nb in (1, 2):
             try:
                 eng.set_variant(op, cfg, nb)

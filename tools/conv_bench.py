@@ -22,7 +22,7 @@ ap.add_argument('--hw', type=int, default=40, help='feature-map height = width a
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
 ap.add_argument('--dtype', default='f16')
-ap.add_argument('--variant', default='', help='force a kernel variant: cfg,nbuf (cfg 0..4 = tiles A..E, 5/6 = streaming 1x1)')
+ap.add_argument('--variant', default='', help='force a kernel variant: cfg,nbuf (cfg 0..5 = tiles A..F, 16 / 17 = streaming 1x1 with 64 / 128 couts per wave)')
 ap.add_argument('--stamps', action='store_true', help='needs LP_HIP_LIB=yolo-lp_amd/libyololp_hip_stamps.so (make stamps)')
 args = ap.parse_args()
 

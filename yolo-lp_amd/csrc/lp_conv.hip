@@ -26,6 +26,7 @@ ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
         case CFG_C: wc = 1; break;
         case CFG_D: wgc = 2; wgp = 4; break;
         case CFG_E: wc = 1; wgc = 2; wgp = 2; break;
+        case CFG_F: wc = 1; wgc = 4; wgp = 2; break;
     }
     s.WP = wp;
     s.WGC = wgc;

@@ -933,10 +933,10 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
 extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int nbuf) {
     if (!e || !e->finalized || op_idx < 0 || op_idx >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_set_op_variant: op index");
     Op& op = e->ops[op_idx];
-    if (op.kind == OP_HEAD_CLS) {        // cfg 7: row writer; the op's packing tile (2 = C) selects the tiled kernel again
-        if (cfg == 7 && !rows_fits(e, op)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the row-writer kernel does not fit this op");
-        if (cfg != 7 && cfg != op.cfg) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: head_cls takes cfg 7 or its packing tile");
-        op.rows = cfg == 7;
+    if (op.kind == OP_HEAD_CLS) {        // LP_VARIANT_ROWS: row writer; the op's packing tile (2 = C) selects the tiled kernel again
+        if (cfg == LP_VARIANT_ROWS && !rows_fits(e, op)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the row-writer kernel does not fit this op");
+        if (cfg != LP_VARIANT_ROWS && cfg != op.cfg) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: head_cls takes LP_VARIANT_ROWS or its packing tile");
+        op.rows = cfg == LP_VARIANT_ROWS;
         e->tuned.erase({e->B, e->H, e->W});
         if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
         return LP_OK;
@@ -944,8 +944,8 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
-    if (cfg == 5 || cfg == 6) {
-        const int wc = cfg == 5 ? 2 : 4;
+    if (cfg == LP_VARIANT_STREAM64 || cfg == LP_VARIANT_STREAM128) {
+        const int wc = cfg == LP_VARIANT_STREAM64 ? 2 : 4;
         if (!stream_fits(e, op, wc) || nbuf != 2)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the streaming 1x1 kernel does not fit this op");
         op.stream_wc = wc;
@@ -964,8 +964,8 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
-    const bool stream = e->ops[op].stream_wc != 0;   // reported as cfg 5 / 6 (2 / 4 cout tiles per wave), nbuf = ring depth
-    if (cfg) *cfg = e->ops[op].rows ? 7 : stream ? (e->ops[op].stream_wc == 2 ? 5 : 6) : e->ops[op].cfg;
+    const bool stream = e->ops[op].stream_wc != 0;
+    if (cfg) *cfg = e->ops[op].rows ? LP_VARIANT_ROWS : stream ? (e->ops[op].stream_wc == 2 ? LP_VARIANT_STREAM64 : LP_VARIANT_STREAM128) : e->ops[op].cfg;
     if (nbuf) *nbuf = stream ? e->ops[op].stream_rd : e->ops[op].nbuf;
     return LP_OK;
 }

@@ -28,7 +28,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- conv launch description ----------------------------------------------------------------------
 enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
-enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*64 x 128, 4 waves of 32x64*/, CFG_COUNT = 5 };
+enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*64 x 128, 4 waves of 32x64*/, CFG_F = 5 /*128 x 128, 8 waves of 32x64*/, CFG_COUNT = 6 };
 
 struct ConvSrc {
     const void* ptr;
