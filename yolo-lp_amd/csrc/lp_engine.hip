@@ -383,7 +383,9 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         const int st = op.kind == OP_CONV ? op.stride : 1;
         int cout_store;
         if (op.kind == OP_HEAD_CLS) { op.mode = MODE_PRED; op.cfg = getenv("LP_PRED_CFG") ? atoi(getenv("LP_PRED_CFG")) : CFG_C; cout_store = op.cout; }
-        else if (op.kind == OP_HEAD_BOX) { op.mode = MODE_DECODE; op.cfg = CFG_A; cout_store = op.cout; }
+        else if (op.kind == OP_HEAD_BOX) {   // the whole row of box / corner logits must sit in one cout tile: 12 (no DFL) fits 32
+            op.mode = MODE_DECODE; op.cfg = op.cout <= 32 ? CFG_C : CFG_A; cout_store = op.cout;
+        }
         else {
             op.mode = MODE_ACT;
             cout_store = e->tensors[op.dst].cs;
