@@ -76,6 +76,7 @@ class Engine:
         self.neck_ids = []
         self.tuned = set()         # (B, H, W) shapes whose per-layer kernel variants were autotuned
         self.autotune = os.environ.get('LP_AUTOTUNE', '1') != '0'
+        self.max_tuned_shapes = 32   # a directory of oddly sized frames must not pay the tuner for every new shape
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
         self._graph_pred = None
         self.input_id = self.tensor(3, 0)
@@ -365,7 +366,7 @@ class Engine:
                 pred = self._graph_pred
             else:
                 pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
-            if self.autotune and self.bound not in self.tuned:
+            if self.autotune and self.bound not in self.tuned and len(self.tuned) < self.max_tuned_shapes:
                 # first batch of this shape: time the kernel variants of every conv layer in place, keep the best
                 abi.check(self.lib.lp_engine_autotune(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
                                                       ctypes.c_void_p(pred.data_ptr()), self._stream(), 5),
