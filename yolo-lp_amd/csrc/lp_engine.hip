@@ -294,14 +294,17 @@ static void put_elem(unsigned char* dst, size_t idx, float v, int dtype) {
     }
 }
 
+// Weight-packing class (cout tile of 128, 64 or 32 rows) of a layer: the least padded output channels, where a row of the
+// 32-row class counts 1.6x -- its kernels (32x64 wave tiles, one LDS stage) run at ~60 % of the rate of the others, so a
+// 96-channel layer is better off padded to 128 rows of the 64-row class.  Ties go to the larger tile.
 static int pick_cfg(int dtype, int ksize, int stride, int cout_store) {
     int best = CFG_A;
-    long best_pad = -1;
-    const int cfgs[3] = {CFG_A, CFG_B, CFG_C};  // larger cout tile first: wins ties
+    long best_cost = -1;
+    const int cfgs[3] = {CFG_A, CFG_B, CFG_C};
     for (int k = 0; k < 3; ++k) {
         const ConvShape s = conv_shape(dtype, cfgs[k], ksize, stride);
-        const long pad = (long)ceil_div(cout_store, s.CB) * s.CB;
-        if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = cfgs[k]; }
+        const long cost = (long)ceil_div(cout_store, s.CB) * s.CB * (cfgs[k] == CFG_C ? 16 : 10);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cfgs[k]; }
     }
     return best;
 }
