@@ -21,7 +21,7 @@ if ROOT not in sys.path:
 
 METRIC = 'images/sec (640×640) end-to-end detect+NMS, yololps, 1/2/4/8 MI355X'
 PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
-SIGMA = {'yololps': 0.25, 'yololpn': 0.6, 'yolov6m': 0.25}       # predictor-weight scale of the synthetic recipe
+SIGMA = {'yololps': 0.25, 'yololpn': 0.6, 'yolov6m': 0.25, 'yolov6s6': 0.25, 'yolov6m6': 0.25}   # predictor-weight scale of the synthetic recipe (the P6 assemblies are extra configs)
 
 
 def parse():
