@@ -105,7 +105,9 @@ int lp_engine_add_head_box(lp_engine* e, int src, int level, int reg_bins, const
 /* Freeze the graph and pack the weights for the MFMA kernels (host side). */
 int lp_engine_finalize(lp_engine* e, int n_levels);
 size_t lp_engine_weight_bytes(const lp_engine* e);
-/* Copy the packed weights into caller-owned device memory (>= lp_engine_weight_bytes, 256-B aligned). */
+/* Copy the packed weights into caller-owned device memory (>= lp_engine_weight_bytes, 256-B aligned).  The buffer must
+ * stay alive and writable while the engine is used: its first 256 bytes are the kernels' zero page and a 16-byte scratch
+ * granule (target of stores that must not land anywhere else). */
 int lp_engine_upload(lp_engine* e, void* dev_weights, void* stream);
 
 /* Activation arena for a given input shape (H, W multiples of 32). */
