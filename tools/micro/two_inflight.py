@@ -1,0 +1,46 @@
+"""Experiment: two batches in flight.  Steps i and i+1 run their forwards on two engines (two arenas) and two HIP streams,
+so the kernels of consecutive steps interleave on the GPU; NMS of every step on a third stream.  Every step still runs
+the whole path on its own batch of 32 images."""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from yolov6.utils.synth import build_synthetic
+from yolov6.utils.torch_utils import fuse_model
+from yolov6.layers.common import RepVGGBlock
+from yolov6.hip import runtime
+from yolov6.hip.runtime import Engine
+
+m = build_synthetic('configs/yololps.py', sigma=0.25)
+m = fuse_model(m).eval()
+for l in m.modules():
+    if isinstance(l, RepVGGBlock): l.switch_to_deploy()
+m = m.cuda().half()
+B = 32
+xs = [torch.rand(B, 3, 640, 640, generator=torch.Generator().manual_seed(1234 + i)).cuda().half() for i in range(2)]
+NE = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+engines = [Engine.from_model(m, torch.float16, torch.device('cuda:0')) for _ in range(NE)]
+streams = [torch.cuda.Stream() for _ in range(NE)]
+s_post = torch.cuda.Stream()
+for e, s in zip(engines, streams):
+    with torch.cuda.stream(s):
+        e.forward(xs[0])
+torch.cuda.synchronize()
+
+def step(i):
+    e, s = engines[i % NE], streams[i % NE]
+    with torch.cuda.stream(s):
+        pred = e.forward(xs[i % 2])
+        ready = torch.cuda.Event(); ready.record(s)
+    s_post.wait_event(ready)
+    pred.record_stream(s_post)
+    with torch.cuda.stream(s_post):
+        return runtime.nms_padded(pred, 0.4, 0.45, 1000)
+
+with torch.no_grad():
+    for i in range(6): step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 40
+    for i in range(K): out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print('%d engine(s) in flight: %.1f images/s, %.3f ms per step' % (NE, K * B / dt, dt / K * 1e3))
