@@ -27,7 +27,7 @@ SIGMA = {'yololps': 0.25, 'yololpn': 0.6, 'yolov6m': 0.25, 'yolov6s6': 0.25, 'yo
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--model', default='yololps', choices=list(SIGMA))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--max-det', type=int, default=1000)
     ap.add_argument('--no-overlap', action='store_true', help='run forward and NMS on one stream (default: NMS of step i on a '
                     'second stream under the forward of step i+1)')
+    ap.add_argument('--inflight', type=int, default=6, help='batches in flight on the GPU: consecutive steps run on this many '
+                    'engines (arenas + streams), see yolov6/core/pipeline.py; 1 = one forward at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
@@ -121,25 +123,44 @@ def main():
             layer.switch_to_deploy()
     model = model.to(dev).to(tdt)
     B = args.batch
-    x = torch.rand(B, 3, args.size, args.size, generator=torch.Generator().manual_seed(1234 + rank)).to(dev).to(tdt)
+    overlap = not args.no_overlap
+    depth = max(1, args.inflight) if overlap else 1
+    # one synthetic batch per slot in flight, all resident in HBM before the timed region
+    xs = [torch.rand(B, 3, args.size, args.size, generator=torch.Generator().manual_seed(1234 + rank + 1000 * k)).to(dev).to(tdt)
+          for k in range(depth)]
+    x = xs[0]
     eng = runtime.engine_for(model)
 
     gathered = None
-    # Two HIP streams: the forward of step i+1 (MFMA-bound conv kernels) overlaps the NMS (+ all-gather) of step i
-    # (bandwidth / latency-bound, one workgroup per image in its last two kernels).  Every step still runs the whole
-    # path; pred is a fresh buffer per step, so the stages only meet through the recorded events.
-    overlap = not args.no_overlap
+    # Streams.  (1) The NMS (+ all-gather) of a step -- bandwidth / latency-bound, one workgroup per image in its last two
+    # kernels -- runs on a post stream under the forwards of the following steps.  (2) `depth` batches are in flight:
+    # consecutive steps run their forwards on `depth` engines (own arena + streams, yolov6/core/pipeline.py), so that the
+    # workgroups of one batch's kernels fill the CU slots another batch's kernels leave empty (at 32 images the 40x40 and
+    # 20x20 layers cannot fill 256 CUs evenly).  Every step still runs the whole path on its own batch; pred is a fresh
+    # buffer per step, the stages only meet through recorded events.
     s_fwd = torch.cuda.current_stream(dev)
     s_post = torch.cuda.Stream(dev) if overlap else s_fwd
+    pipe = None
+    if depth > 1:
+        from yolov6.core.pipeline import InflightForward
+        pipe = InflightForward(model, depth)
+    nstep = [0]
 
     def step():
         nonlocal gathered
-        pred = eng.forward(x)
-        if overlap:
-            ready = torch.cuda.Event()
-            ready.record(s_fwd)
+        k = nstep[0] % depth
+        nstep[0] += 1
+        if pipe is not None:
+            pred, ready = pipe.submit(xs[k], fresh=False)      # the synthetic batches were made before the timed region
             s_post.wait_event(ready)
             pred.record_stream(s_post)
+        else:
+            pred = eng.forward(x)
+            if overlap:
+                ready = torch.cuda.Event()
+                ready.record(s_fwd)
+                s_post.wait_event(ready)
+                pred.record_stream(s_post)
         with torch.cuda.stream(s_post):
             det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
             if world > 1:
@@ -147,8 +168,16 @@ def main():
                 return gathered
         return det, count
 
+    def join():     # the measuring stream waits for everything enqueued on the other streams
+        if pipe is not None:
+            for st in pipe.streams:
+                s_fwd.wait_stream(st)
+        if s_post is not s_fwd:
+            s_fwd.wait_stream(s_post)
+
     with torch.no_grad():
-        out = step()            # set-up, not a step of the measurement: binds the arena, tunes the kernel variants, allocates the NMS workspace
+        for _ in range(depth):   # set-up, not steps of the measurement: every engine binds its arena and tunes its kernel variants
+            out = step()
         for _ in range(args.warmup):
             out = step()
         torch.cuda.synchronize()
@@ -160,6 +189,7 @@ def main():
         ev0.record()
         for _ in range(args.steps):
             out = step()
+        join()
         ev1.record()
         t_issue = time.perf_counter() - t0          # host time to enqueue all steps
         torch.cuda.synchronize()
@@ -222,7 +252,8 @@ def main():
                                    '(sigma %.2f), conf %.2f iou %.2f max_det %d'
                                    % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
                        'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
-                       'streams': 'forward || NMS(+gather) of the previous step' if overlap else 'single stream',
+                       'streams': ('%d batches in flight (one engine + arena + streams each) || NMS(+gather) on a post stream' % depth
+                                   if depth > 1 else 'forward || NMS(+gather) of the previous step') if overlap else 'single stream',
                        'mean_detections_per_image': round(counts, 1),
                        'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
                        'device_ms_per_step': round(ev0.elapsed_time(ev1) / args.steps, 3)},

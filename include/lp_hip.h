@@ -149,6 +149,9 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);
+/* Copy the tuned choices (all shapes) of an engine built from the same graph and dtype, e.g. to the other engines of a
+ * several-batches-in-flight pipeline, instead of tuning each. */
+int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src);
 
 /* ---------------------------------------------------------------------------------------------------
  * Post-processing.  Replaces non_max_suppression (yolov6/utils/nms.py:31-130) including its call of

@@ -333,6 +333,25 @@ def test_eval_entry_point_val_on_gpu(tmp_path, monkeypatch):
     assert metrics == lp_metric.finish(got_c)
 
 
+def test_inflight_pipeline_matches_single_engine():
+    """Several batches in flight (yolov6/core/pipeline.py): every batch gets the bits a single engine gives it, the
+    other engines take over the first engine's tuning, and the results do not depend on the interleaving."""
+    from yolov6.core.pipeline import InflightForward
+    from yolov6.hip import runtime
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=0.25, sigma=1.0).cuda().half()
+    xs = [torch.rand(3, 3, 128, 192, generator=torch.Generator().manual_seed(50 + i)).cuda().half() for i in range(7)]
+    with torch.no_grad():
+        ref = [m(x)[0].clone() for x in xs]                      # one engine, one batch at a time
+        pipe = InflightForward(m, depth=3)
+        outs = [pipe.submit(x) for x in xs]
+        for (pred, done), r in zip(outs, ref):
+            done.synchronize()
+            assert torch.equal(pred, r)
+    eng0 = runtime.engine_for(m)
+    assert pipe.engines[0] is eng0 and all(e.tuned == eng0.tuned and len(e.tuned) == 1 for e in pipe.engines)
+
+
 def test_gather_detections_rccl_on_side_stream():
     """The all-gather of padded detections through RCCL (backend nccl), issued on a side stream like bench.py does;
     one rank is all a one-GPU box offers, so this checks the plumbing (RCCL loads, the collective runs on our tensors

@@ -935,6 +935,29 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     return LP_OK;
 }
 
+extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
+    if (!dst || !src || !dst->finalized || !src->finalized) return fail(LP_ERR_STATE, "lp_engine_copy_tuning: finalize both engines first");
+    if (dst->dtype != src->dtype || dst->ops.size() != src->ops.size()) return fail(LP_ERR_ARG, "lp_engine_copy_tuning: engines differ");
+    for (size_t i = 0; i < src->ops.size(); ++i) {
+        const Op &a = src->ops[i], &b = dst->ops[i];
+        if (a.kind != b.kind || a.ksize != b.ksize || a.stride != b.stride || a.cout != b.cout || a.nchunks != b.nchunks || a.nct != b.nct)
+            return fail(LP_ERR_ARG, "lp_engine_copy_tuning: engines were built from different graphs");
+    }
+    dst->tuned = src->tuned;      // applied by lp_engine_bind for the shapes it contains
+    if (dst->arena) {
+        auto it = dst->tuned.find({dst->B, dst->H, dst->W});
+        if (it != dst->tuned.end())
+            for (size_t i = 0; i < dst->ops.size(); ++i) {
+                Op& op = dst->ops[i];
+                op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5];
+                int rc = prepare_op(dst, i);
+                if (rc) return rc;
+            }
+    }
+    return LP_OK;
+}
+
 extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int nbuf) {
     if (!e || !e->finalized || op_idx < 0 || op_idx >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_set_op_variant: op index");
     Op& op = e->ops[op_idx];

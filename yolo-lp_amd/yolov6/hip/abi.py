@@ -55,6 +55,7 @@ SYMBOLS = {
     'lp_engine_autotune': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'lp_engine_op_variant': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     'lp_engine_set_op_variant': (c_int, [c_void_p, c_int, c_int, c_int]),
+    'lp_engine_copy_tuning': (c_int, [c_void_p, c_void_p]),
     'lp_nms_workspace_bytes': (c_size_t, [c_int, c_int]),
     'lp_preprocess_letterbox': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),

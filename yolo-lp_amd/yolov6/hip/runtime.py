@@ -334,6 +334,11 @@ class Engine:
         self.graph = bool(enable)
         abi.check(self.lib.lp_engine_set_graph(self.h, 1 if enable else 0), 'lp_engine_set_graph')
 
+    def copy_tuning(self, other):
+        """Take over the tuned kernel variants (all shapes) of ``other``, an engine of the same model and dtype."""
+        abi.check(self.lib.lp_engine_copy_tuning(self.h, other.h), 'lp_engine_copy_tuning')
+        self.tuned = set(other.tuned)
+
     def set_variant(self, op, cfg, nbuf):
         """Force the kernel variant of conv op ``op`` (see lp_engine_set_op_variant); switches the autotuner off."""
         self.autotune = False
