@@ -333,6 +333,31 @@ def test_eval_entry_point_val_on_gpu(tmp_path, monkeypatch):
     assert metrics == lp_metric.finish(got_c)
 
 
+def test_graph_recapture_while_previous_replay_is_in_flight():
+    """hipGraph mode with an input pointer that changes every call (re-capture each time) on a side stream and without host
+    synchronisation: the previous executable graph may still be running when it is replaced -- it must be kept alive until
+    its launch has finished (this used to crash the process)."""
+    from yolov6.hip import runtime
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=0.25, sigma=1.0).cuda().half()
+    xs = [torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(70 + i)).cuda().half() for i in range(2)]
+    with torch.no_grad():
+        ref = [m(x)[0].clone() for x in xs]
+        eng = runtime.engine_for(m)
+        eng.set_graph(True)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.stream(side):
+                for i in range(40):
+                    pred = eng.forward(xs[i % 2])
+                last = pred.clone()
+            side.synchronize()
+        finally:
+            eng.set_graph(False)
+    assert torch.equal(last, ref[39 % 2])
+
+
 def test_inflight_pipeline_matches_single_engine():
     """Several batches in flight (yolov6/core/pipeline.py): every batch gets the bits a single engine gives it, the
     other engines take over the first engine's tuning, and the results do not depend on the interleaving."""

@@ -17,8 +17,12 @@ m = m.cuda().half()
 B = 32
 xs = [torch.rand(B, 3, 640, 640, generator=torch.Generator().manual_seed(1234 + i)).cuda().half() for i in range(2)]
 NE = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+GRAPH = len(sys.argv) > 2 and sys.argv[2] == 'graph'
 engines = [Engine.from_model(m, torch.float16, torch.device('cuda:0')) for _ in range(NE)]
 streams = [torch.cuda.Stream() for _ in range(NE)]
+nms_done = [None] * NE
+if GRAPH:
+    for e in engines: e.set_graph(True)
 s_post = torch.cuda.Stream()
 for e, s in zip(engines, streams):
     with torch.cuda.stream(s):
@@ -27,13 +31,18 @@ torch.cuda.synchronize()
 
 def step(i):
     e, s = engines[i % NE], streams[i % NE]
+    if GRAPH and nms_done[i % NE] is not None:
+        s.wait_event(nms_done[i % NE])      # the engine's persistent pred buffer is free again
     with torch.cuda.stream(s):
         pred = e.forward(xs[i % 2])
         ready = torch.cuda.Event(); ready.record(s)
     s_post.wait_event(ready)
     pred.record_stream(s_post)
     with torch.cuda.stream(s_post):
-        return runtime.nms_padded(pred, 0.4, 0.45, 1000)
+        out = runtime.nms_padded(pred, 0.4, 0.45, 1000)
+        if GRAPH:
+            nms_done[i % NE] = torch.cuda.Event(); nms_done[i % NE].record(s_post)
+        return out
 
 with torch.no_grad():
     for i in range(6): step(i)
@@ -43,4 +52,4 @@ with torch.no_grad():
     for i in range(K): out = step(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print('%d engine(s) in flight: %.1f images/s, %.3f ms per step' % (NE, K * B / dt, dt / K * 1e3))
+print('%d engine(s) in flight%s: %.1f images/s, %.3f ms per step' % (NE, ' + hipGraph' if GRAPH else '', K * B / dt, dt / K * 1e3))

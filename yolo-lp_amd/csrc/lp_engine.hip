@@ -89,6 +89,8 @@ struct lp_engine {
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {nullptr, nullptr, nullptr};
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
     hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;   // stream of the last hipGraphLaunch (synchronised before the graph is destroyed)
+    bool graph_stream_valid = false;
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
     const void* graph_x = nullptr;    // the capture is valid for exactly these pointers / dtype / tuning state
     float* graph_pred = nullptr;
@@ -120,7 +122,10 @@ extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
 extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph_exec) {
+        if (e->graph_stream_valid) (void)hipStreamSynchronize(e->graph_stream);
+        (void)hipGraphExecDestroy(e->graph_exec);
+    }
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (hipEvent_t ev : e->op_event) if (ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
@@ -766,7 +771,11 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
     const bool valid = e->graph_exec && e->graph_x == x && e->graph_pred == pred && e->graph_x_dtype == x_dtype &&
                        e->graph_epoch == e->epoch;
     if (!valid) {
-        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph_exec) {     // its last launch may still be running: an executable graph must outlive it
+            if (e->graph_stream_valid) (void)hipStreamSynchronize(e->graph_stream);
+            (void)hipGraphExecDestroy(e->graph_exec);
+            e->graph_exec = nullptr;
+        }
         rc = ensure_lanes(e);
         if (rc) return rc;
         hipGraph_t g = nullptr;
@@ -785,6 +794,8 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
         e->graph_epoch = e->epoch;
     }
     LP_HIP_CHECK(hipGraphLaunch(e->graph_exec, main_st));
+    e->graph_stream = main_st;
+    e->graph_stream_valid = true;
     return LP_OK;
 }
 
