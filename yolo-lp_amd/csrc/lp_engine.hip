@@ -88,14 +88,18 @@ struct lp_engine {
     std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {nullptr, nullptr, nullptr};
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
-    hipGraphExec_t graph_exec = nullptr;
-    hipStream_t graph_stream = nullptr;   // stream of the last hipGraphLaunch (synchronised before the graph is destroyed)
-    bool graph_stream_valid = false;
+    struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
+        hipGraphExec_t exec = nullptr;
+        const void* x = nullptr;
+        float* pred = nullptr;
+        int x_dtype = -1;
+        unsigned long long epoch = 0, last_use = 0;
+        hipStream_t stream = nullptr;  // stream of its last launch: synchronised before the executable graph is destroyed
+    };
+    std::vector<CachedGraph> graphs;   // a few, so that alternating buffers do not re-capture (and destroy) every call
+    unsigned long long graph_clock = 0;
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
-    const void* graph_x = nullptr;    // the capture is valid for exactly these pointers / dtype / tuning state
-    float* graph_pred = nullptr;
-    int graph_x_dtype = -1;
-    unsigned long long graph_epoch = 0, epoch = 1;   // epoch changes whenever launches are re-prepared
+    unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
     std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows}
 };
@@ -122,9 +126,9 @@ extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
 extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-    if (e->graph_exec) {
-        if (e->graph_stream_valid) (void)hipStreamSynchronize(e->graph_stream);
-        (void)hipGraphExecDestroy(e->graph_exec);
+    for (auto& g : e->graphs) {
+        if (g.stream) (void)hipStreamSynchronize(g.stream);
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     }
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (hipEvent_t ev : e->op_event) if (ev) (void)hipEventDestroy(ev);
@@ -768,13 +772,24 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
     // hipGraph path: the ~80 launches (and the lane fork/join events) of one forward are captured once per
     // (input pointer, output pointer, dtype, launch geometry) and replayed with a single hipGraphLaunch -- what the
     // per-image loop of Inferer needs, where the forward is launch-bound.
-    const bool valid = e->graph_exec && e->graph_x == x && e->graph_pred == pred && e->graph_x_dtype == x_dtype &&
-                       e->graph_epoch == e->epoch;
-    if (!valid) {
-        if (e->graph_exec) {     // its last launch may still be running: an executable graph must outlive it
-            if (e->graph_stream_valid) (void)hipStreamSynchronize(e->graph_stream);
-            (void)hipGraphExecDestroy(e->graph_exec);
-            e->graph_exec = nullptr;
+    constexpr size_t kMaxGraphs = 8;
+    lp_engine::CachedGraph* hit = nullptr;
+    for (auto& g : e->graphs)
+        if (g.exec && g.x == x && g.pred == pred && g.x_dtype == x_dtype && g.epoch == e->epoch) hit = &g;
+    if (!hit) {
+        // retire stale captures (re-tuned / re-bound engine) and, when the cache is full, the least recently used one; an
+        // executable graph must outlive its last launch, so that launch's stream is synchronised first
+        for (size_t i = 0; i < e->graphs.size();) {
+            auto& g = e->graphs[i];
+            bool drop = g.epoch != e->epoch;
+            if (!drop && e->graphs.size() >= kMaxGraphs) {
+                drop = true;
+                for (const auto& o : e->graphs) drop = drop && o.last_use >= g.last_use;
+            }
+            if (!drop) { ++i; continue; }
+            if (g.stream) (void)hipStreamSynchronize(g.stream);
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            e->graphs.erase(e->graphs.begin() + (long)i);
         }
         rc = ensure_lanes(e);
         if (rc) return rc;
@@ -785,17 +800,20 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
         hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(LP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        ce = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+        lp_engine::CachedGraph cg;
+        ce = hipGraphInstantiate(&cg.exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
-        if (ce != hipSuccess) { e->graph_exec = nullptr; return fail(LP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); }
-        e->graph_x = x;
-        e->graph_pred = pred;
-        e->graph_x_dtype = x_dtype;
-        e->graph_epoch = e->epoch;
+        if (ce != hipSuccess) return fail(LP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce));
+        cg.x = x;
+        cg.pred = pred;
+        cg.x_dtype = x_dtype;
+        cg.epoch = e->epoch;
+        e->graphs.push_back(cg);
+        hit = &e->graphs.back();
     }
-    LP_HIP_CHECK(hipGraphLaunch(e->graph_exec, main_st));
-    e->graph_stream = main_st;
-    e->graph_stream_valid = true;
+    LP_HIP_CHECK(hipGraphLaunch(hit->exec, main_st));
+    hit->stream = main_st;
+    hit->last_use = ++e->graph_clock;
     return LP_OK;
 }
 

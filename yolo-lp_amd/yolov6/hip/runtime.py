@@ -79,6 +79,7 @@ class Engine:
         self.max_tuned_shapes = 32   # a directory of oddly sized frames must not pay the tuner for every new shape
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
         self._graph_pred = None
+        self._graph_x = None       # graph mode: persistent staging copy of the input (fixed address)
         self.input_id = self.tensor(3, 0)
         abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
 
@@ -365,10 +366,16 @@ class Engine:
         B, _, H, W = x.shape
         with torch.cuda.device(self.device):
             self.bind(B, H, W)
-            if self.graph:      # fixed output address so that the captured graph stays valid
+            if self.graph:      # fixed input and output addresses: one captured graph per shape, never re-captured
                 if self._graph_pred is None or self._graph_pred.shape != (B, self.n_anchors, abi.LP_PRED_COLS):
                     self._graph_pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
                 pred = self._graph_pred
+                gx = getattr(self, '_graph_x', None)
+                if gx is None or gx.shape != x.shape or gx.dtype != x.dtype:
+                    gx = self._graph_x = torch.empty_like(x)
+                if gx.data_ptr() != x.data_ptr():
+                    gx.copy_(x)         # a frame-sized copy on the caller's stream; the graph reads the staging buffer
+                x = gx
             else:
                 pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
             if self.autotune and self.bound not in self.tuned and len(self.tuned) < self.max_tuned_shapes:
