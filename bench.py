@@ -129,6 +129,7 @@ def main():
     xs = [torch.rand(B, 3, args.size, args.size, generator=torch.Generator().manual_seed(1234 + rank + 1000 * k)).to(dev).to(tdt)
           for k in range(depth)]
     x = xs[0]
+    torch.cuda.synchronize(dev)        # the batches are complete in HBM before any side stream reads them
     eng = runtime.engine_for(model)
 
     gathered = None
