@@ -25,6 +25,7 @@ class InflightForward:
             self.engines = [first] + [runtime.Engine.from_model(model, first.dtype, self.device) for _ in range(self.depth - 1)]
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+        torch.cuda.synchronize(self.device)     # the engines' packed weights are uploaded before any side stream uses them
         self._next = 0
 
     def submit(self, x, fresh=True):
