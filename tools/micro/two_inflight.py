@@ -1,4 +1,5 @@
-"""Experiment: two batches in flight.  Steps i and i+1 run their forwards on two engines (two arenas) and two HIP streams,
+"""Experiment: several batches in flight (what became yolov6/core/pipeline.py).  Optional second argument `graph`: every
+engine replays its forward as one hipGraph -- +3 % in this script, nothing in bench.py, so it is not in the product.  Steps i and i+1 run their forwards on two engines (two arenas) and two HIP streams,
 so the kernels of consecutive steps interleave on the GPU; NMS of every step on a third stream.  Every step still runs
 the whole path on its own batch of 32 images."""
 import os, sys, time, torch
