@@ -143,9 +143,12 @@ int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, voi
  * is the same fp32 sum in the same K order, so results do not depend on the choice.  lp_engine_op_variant reports
  * the current choice of an op: cfg = a workgroup tile of the implicit-GEMM kernel (0..5 = A..F) with
  * nbuf = LDS ring depth 1 or 2, or LP_VARIANT_STREAM64 / LP_VARIANT_STREAM128 (streaming 1x1 kernel with 64 / 128 output
- * channels per wave, nbuf 2), or LP_VARIANT_ROWS (row-writer form of a head_cls op, nbuf 1).
+ * channels per wave, nbuf 2), or LP_VARIANT_ROWS (row-writer form of a head_cls op, nbuf 1), or LP_VARIANT_PIPE_* (pipelined
+ * 3x3 stride-1 kernel, nbuf 3).
  * lp_engine_set_op_variant forces one (tests, experiments): LP_ERR_UNSUPPORTED if it does not fit the op. */
-enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18 };
+enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18,
+       /* pipelined 3x3 stride-1 kernel (persistent, 3-slot LDS ring, nbuf 3): 128 couts x 256 px, 64 x 512, 128 x 128 */
+       LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34 };
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);

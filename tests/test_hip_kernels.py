@@ -433,18 +433,83 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     base, tried = None, 0
-    for cfg in list(range(8)) + [16, 17]:
-        for nb in (1, 2):
-            try:
-                eng.set_variant(op, cfg, nb)
-            except RuntimeError:
-                continue
-            eng.tensor_view(dst).zero_()
-            _run(eng, B, hw << sl, hw << sl)
-            out = eng.tensor_view(dst).clone()
-            tried += 1
-            if base is None:
-                base = out
-            else:
-                assert torch.equal(out, base), (cfg, nb)
+    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3)]:   # 32..34: LP_VARIANT_PIPE_*
+        try:
+            eng.set_variant(op, cfg, nb)
+        except RuntimeError:
+            continue
+        eng.tensor_view(dst).zero_()
+        _run(eng, B, hw << sl, hw << sl)
+        out = eng.tensor_view(dst).clone()
+        tried += 1
+        if base is None:
+            base = out
+        else:
+            assert torch.equal(out, base), (cfg, nb)
     assert tried >= 2
+
+
+PIPE_CASES = [
+    # (cin list, cout, act, residual, h, w, B): the pipelined 3x3 stride-1 kernel (LP_VARIANT_PIPE_*) on shapes where a
+    # persistent workgroup walks several tiles (more tiles than CUs), single-chunk layers (the ring outruns a tile), ragged
+    # maps, concat sources, partial cout tiles and the residual epilogue
+    ([64], 64, 'relu', False, 160, 160, 6),
+    ([128], 128, 'relu', False, 40, 40, 40),
+    ([256], 256, 'silu', False, 20, 20, 70),
+    ([64, 64], 128, 'relu', False, 40, 40, 40),
+    ([16], 64, 'relu', False, 40, 40, 3),
+    ([8], 128, 'none', False, 24, 40, 2),
+    ([96], 192, 'relu', True, 13, 27, 5),
+    ([64], 64, 'relu', True, 33, 17, 3),
+    ([512], 512, 'relu', False, 20, 20, 2),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', PIPE_CASES, ids=lambda c: '%s-%d-%s%s-%dx%dx%d' % ('+'.join(map(str, c[0])), c[1], c[2], '-res' if c[3] else '', c[6], c[4], c[5]))
+def test_conv3x3_pipe(case, dtype):
+    """Pipelined 3x3 kernel: bit-identical to the generic implicit-GEMM kernel (same K order, same epilogue arithmetic) and
+    within the stated tolerance of F.conv2d in fp32."""
+    from yolov6.hip import abi
+    cins, cout, act, use_res, h, w, B = case
+    sl = 5
+    eng = _engine(dtype)
+    eng.autotune = False
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, 3, 3), 1, (2.0 / (cin * 9)) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    res_id = eng.tensor(cout, sl) if use_res else None
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, bias, 3, 1, act_id, sl, res=res_id, alpha=0.75)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    xs = [_rand((B, c, h, w), 10 + i) for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()
+    for t, x in zip(srcs, xs):
+        _fill(eng, t, x)
+    res = _rand((B, cout, h, w), 20) if use_res else None
+    if use_res:
+        _fill(eng, res_id, res)
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)
+    base = eng.tensor_view(dst).clone()
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(wt), bias, padding=1)
+    ref = {'none': lambda t: t, 'relu': F.relu, 'silu': F.silu}[act](ref)
+    if use_res:
+        ref = q(ref) + 0.75 * q(res)
+    assert rel_err(base.float().cpu(), ref) <= TOL[dtype]
+    tried = 0
+    for cfg in (32, 33, 34):
+        try:
+            eng.set_variant(op, cfg, 3)
+        except RuntimeError:
+            continue
+        tried += 1
+        for rep in range(2):                               # twice: a stale ring slot or a missed wait shows as run-to-run noise
+            eng.tensor_view(dst).fill_(float('nan'))
+            _run(eng, B, H, W)
+            out = eng.tensor_view(dst)
+            assert torch.equal(out, base), (cfg, rep, float((out.float() - base.float()).abs().max()))
+    assert tried >= 1

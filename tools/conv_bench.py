@@ -53,6 +53,12 @@ print('%s k%d s%d %d->%d @%dx%d B%d variant %s: %.1f us  %.1f TFLOP/s  %.2f TB/s
 
 if stamps is not None:
     st = stamps.view(-1, 8).cpu()
+    clk = st[st[:, 7] == 2].double()
+    if clk.shape[0]:          # pipelined 3x3 kernel: shader clocks / 100 MHz reference ticks per wave
+        ghz = (clk[:, 0] / clk[:, 1].clamp(min=1)) * 0.1
+        print('in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %d waves; wave lifetime median %.1f us, max %.1f us'
+              % (ghz.median(), ghz.min(), ghz.max(), clk.shape[0], clk[:, 1].median() / 100, clk[:, 1].max() / 100))
+        sys.exit(0)
     st = st[st[:, 7] == 1].double()
     n = st.shape[0]
     tot = st[:, 5].mean()

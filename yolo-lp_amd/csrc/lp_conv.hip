@@ -12,6 +12,9 @@ int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
 int conv_stream_launch_bf16(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
 int conv_stream_launch_f32(int wc, const ConvArgs& a, int cb_pack, int lds, hipStream_t st);
 
+int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st);
+int conv_pipe_launch_bf16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st);
+
 int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st);
 int head_rows_launch_bf16(const ConvArgs& a, int cb_pack, hipStream_t st);
 int head_rows_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st);
@@ -154,6 +157,55 @@ int conv_stream_launch(int dtype, int wc, const ConvArgs& a0, int cb_pack, hipSt
         case LP_F32: return conv_stream_launch_f32(wc, a, cb_pack, lds, st);
     }
     return fail(LP_ERR_ARG, "conv1x1 stream: dtype");
+}
+
+// ---- pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc) ----
+ConvShape conv_pipe_shape(int pcfg) {
+    ConvShape s;
+    s.KC = 16;
+    s.NT = 512;
+    s.WP = 2;
+    switch (pcfg) {
+        case PIPE_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
+        case PIPE_F: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
+        default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
+    }
+    s.PB = 32 * s.WP * s.WGP;
+    return s;
+}
+
+bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase) {
+    if (dtype == LP_F32 || pcfg < 0 || pcfg >= PIPE_COUNT || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
+    const ConvShape s = conv_pipe_shape(pcfg);
+    return s.CB == cb_pack && nct * s.CB <= 1024;   // 1024 = PIPE_MAXC (bias table in LDS)
+}
+
+static int g_ncu[16] = {0};
+static int device_cus() {   // CUs of the current device = persistent workgroups of the pipe kernel (one per CU)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!g_ncu[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        g_ncu[dev] = n / 8 * 8;
+    }
+    return g_ncu[dev];
+}
+
+int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
+    const ConvShape s = conv_pipe_shape(pcfg);
+    const int hh = a.TH + 2, hw = a.TW + 2;
+    if (pcfg < 0 || pcfg >= PIPE_COUNT) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");
+    if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || a.hpitch < hw || hh * a.hpitch > s.HPMAX)
+        return fail(LP_ERR_ARG, "conv3x3 pipe: tile does not fit the kernel configuration");
+    if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv3x3 pipe: tiles do not cover the output");
+    if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nct * s.CB > 1024 || a.nphase != 1 || a.out_scale != 1 || a.Ho != a.H || a.Wo != a.W)
+        return fail(LP_ERR_ARG, "conv3x3 pipe: not a 3x3 stride-1 layer this kernel runs");
+    switch (dtype) {
+        case LP_F16: return conv_pipe_launch_f16(pcfg, a, device_cus(), st);
+        case LP_BF16: return conv_pipe_launch_bf16(pcfg, a, device_cus(), st);
+    }
+    return fail(LP_ERR_UNSUPPORTED, "conv3x3 pipe: 16-bit activations only");
 }
 
 // Row-writer form of the class predictors (lp_head_rows.inc): whether the op fits, and the launch.

@@ -49,6 +49,7 @@ struct Op {
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
     int stream_wc = 0, stream_rd = 2;   // stream_wc != 0: the streaming 1x1 kernel (2 or 4 cout tiles per wave) runs this op
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
+    int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -58,7 +59,7 @@ struct Launch {
     ConvArgs a;
     long long pred_off = 0;
     int cfg = 0, mode = 0, ks = 1, st = 1, nbuf = 1;
-    int stream_wc = 0, stream_rd = 2, cb_pack = 0, rows = 0;
+    int stream_wc = 0, stream_rd = 2, cb_pack = 0, rows = 0, pipe = 0;
     bool is_conv = false;
 };
 
@@ -101,7 +102,7 @@ struct lp_engine {
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
     unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows}
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe}
 };
 
 #define LP_MAX_LANES 3
@@ -536,7 +537,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -624,7 +625,8 @@ static int prepare_op(lp_engine* e, size_t idx) {
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
-    const ConvShape s = conv_shape(dt, op.cfg, ks, stv);
+    const int cb_pack = conv_shape(dt, op.cfg, ks, stv).CB;
+    const ConvShape s = op.pipe ? conv_pipe_shape(op.pipe - 1) : conv_shape(dt, op.cfg, ks, stv);
     ConvArgs& a = L.a;
     memset(&a, 0, sizeof(a));
     a.nsrc = op.nsrc;
@@ -680,7 +682,8 @@ static int prepare_op(lp_engine* e, size_t idx) {
     L.stream_wc = op.stream_wc;
     L.stream_rd = op.stream_rd;
     L.rows = op.rows;
-    L.cb_pack = s.CB;
+    L.pipe = op.pipe;
+    L.cb_pack = cb_pack;
     return LP_OK;
 }
 
@@ -696,6 +699,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
+    if (L.mode == MODE_ACT && L.pipe) return conv_pipe_launch(dt, L.pipe - 1, L.a, st);
     if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.a, L.cb_pack, st);
     if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
     if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
@@ -901,7 +905,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         }
         if (!e->launches[i].is_conv || op.mode != MODE_ACT) continue;
         const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
-        int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile, best_wc = 0, best_rd = 2;
+        int best_cfg = op.cfg, best_nb = op.nbuf, best_tile = op.tile, best_wc = 0, best_rd = 2, best_pipe = 0;
         float best_ms = -1.f;
         int trc = LP_OK;
         auto time_current = [&]() -> float {   // best of three rounds of `reps` launches of the op as prepared; < 0: failed
@@ -918,6 +922,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             return ms_min;
         };
         op.stream_wc = 0;
+        op.pipe = 0;
         for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
             if (conv_shape(e->dtype, cfg, 1, 1).CB != cb) continue;
             for (int nb = 1; nb <= (cfg == CFG_C ? 1 : 2); ++nb) {
@@ -949,17 +954,38 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
                 }
             }
         }
+        // 3x3 stride-1 layers: the pipelined kernel reads the same packing
+        int pipe_tile = 0;
+        if (!getenv("LP_NO_PIPE") && op.kind == OP_CONV) {
+            op.cfg = best_cfg; op.nbuf = best_nb; op.stream_wc = 0;
+            for (int pc = 0; pc < PIPE_COUNT; ++pc) {
+                if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase)) continue;
+                int last_th = -1, last_tw = -1;
+                for (int tile = 0; tile < 3; ++tile) {
+                    op.pipe = pc + 1;
+                    op.tile = tile;
+                    if (prepare_op(e, i) != LP_OK) continue;
+                    if (e->launches[i].a.TH == last_th && e->launches[i].a.TW == last_tw) break;
+                    last_th = e->launches[i].a.TH;
+                    last_tw = e->launches[i].a.TW;
+                    const float ms = time_current();
+                    if (ms >= 0.f && (best_ms < 0.f || ms < best_ms)) { best_ms = ms; best_pipe = pc + 1; pipe_tile = tile; }
+                }
+            }
+            op.pipe = 0;
+        }
         if (trc) return fail(trc, "autotune: event timing failed");
         op.cfg = best_cfg;
         op.nbuf = best_nb;
-        op.tile = best_tile;
-        op.stream_wc = best_wc;
+        op.tile = best_pipe ? pipe_tile : best_tile;
+        op.stream_wc = best_pipe ? 0 : best_wc;
         op.stream_rd = best_rd;
+        op.pipe = best_pipe;
         rc = prepare_op(e, i);
         if (rc) return rc;
     }
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -979,7 +1005,7 @@ extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
             for (size_t i = 0; i < dst->ops.size(); ++i) {
                 Op& op = dst->ops[i];
                 op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
-                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6];
                 int rc = prepare_op(dst, i);
                 if (rc) return rc;
             }
@@ -1001,16 +1027,24 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
-    if (cfg == LP_VARIANT_STREAM64 || cfg == LP_VARIANT_STREAM128) {
+    if (cfg >= LP_VARIANT_PIPE_D && cfg <= LP_VARIANT_PIPE_F) {
+        const int pc = cfg - LP_VARIANT_PIPE_D;
+        if (!conv_pipe_fits(e->dtype, pc, cb, ks, stv, op.mode, op.nct, op.nphase) || op.kind != OP_CONV || nbuf != 3)
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the pipelined 3x3 kernel does not fit this op");
+        op.stream_wc = 0;
+        op.pipe = pc + 1;
+    } else if (cfg == LP_VARIANT_STREAM64 || cfg == LP_VARIANT_STREAM128) {
         const int wc = cfg == LP_VARIANT_STREAM64 ? 2 : 4;
         if (!stream_fits(e, op, wc) || nbuf != 2)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the streaming 1x1 kernel does not fit this op");
         op.stream_wc = wc;
         op.stream_rd = nbuf;
+        op.pipe = 0;
     } else {
         if (cfg < 0 || cfg >= CFG_COUNT || conv_shape(e->dtype, cfg, ks, stv).CB != cb || nbuf < 1 || nbuf > (cfg == CFG_C ? 1 : 2))
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: variant does not share the op's weight packing");
         op.stream_wc = 0;
+        op.pipe = 0;
         op.cfg = cfg;
         op.nbuf = nbuf;
     }
@@ -1022,6 +1056,11 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;
+    if (e->ops[op].pipe) {
+        if (cfg) *cfg = LP_VARIANT_PIPE_D + e->ops[op].pipe - 1;
+        if (nbuf) *nbuf = 3;
+        return LP_OK;
+    }
     if (cfg) *cfg = e->ops[op].rows ? LP_VARIANT_ROWS : stream ? (e->ops[op].stream_wc == 2 ? LP_VARIANT_STREAM64 : LP_VARIANT_STREAM128) : e->ops[op].cfg;
     if (nbuf) *nbuf = stream ? e->ops[op].stream_rd : e->ops[op].nbuf;
     return LP_OK;

@@ -30,6 +30,9 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
 enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*64 x 128, 4 waves of 32x64*/, CFG_F = 5 /*128 x 128, 8 waves of 32x64*/, CFG_COUNT = 6 };
 
+// Pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc): workgroup configurations
+enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_COUNT = 3 };
+
 struct ConvSrc {
     const void* ptr;
     int cs;  // stored channels (multiple of 8) = pixel stride in elements
@@ -82,6 +85,11 @@ int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, c
 // weight packing.  conv_stream_lds() < 0: the layer does not fit.
 int conv_stream_lds(int dtype, int wc, int nchunks, int cb_pack);
 int conv_stream_launch(int dtype, int wc, const ConvArgs& a, int cb_pack, hipStream_t st);
+
+// Pipelined 3x3 stride-1 kernel: geometry of configuration `pcfg` (CB = the weight-packing cout tile it reads), and the launch.
+ConvShape conv_pipe_shape(int pcfg);
+bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase);
+int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st);
 
 // Row-writer form of the class predictors (lp_head_rows.inc).
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c);
