@@ -70,12 +70,24 @@ def test_tiny_model_fp32_matches_reference_golden(case, weights, name, deploy):
         assert rel_err(f.float().cpu(), ref) <= 1e-4
 
 
-@pytest.mark.parametrize('dtype,box_tol,prob_tol', [(torch.float16, 2e-2, 2e-2), (torch.bfloat16, 1.5e-1, 1.5e-1)],
-                         ids=['f16', 'bf16'])
+# Stated half-precision tolerances (coordinates as a fraction of the input extent, probabilities absolute): <= 3x the error
+# measured on MI355X (gpurun_out/parity.log, round 2).  fp16: 7.7e-4 / 6.8e-4 / 4.4e-3 of the extent and 2.7e-4 / 1.7e-4 /
+# 8.6e-3 in probability on the three cases; bf16: 5.5e-3 / 3.4e-3 / 5.2e-2 and 4.5e-3 / 2.0e-3 / 9.8e-2 (the yolov6m recipe
+# produces distances of 500 grid units and 8 significant bits are rounded at ~60 chained layers).
+HALF_TOL = {
+    (torch.float16, 'lps_tiny_128x96'): (2.4e-3, 9e-4), (torch.float16, 'lps_tiny_64x160'): (2.1e-3, 6e-4),
+    (torch.float16, 'v6m_tiny_96x128'): (1.4e-2, 2.6e-2),
+    (torch.bfloat16, 'lps_tiny_128x96'): (1.7e-2, 1.4e-2), (torch.bfloat16, 'lps_tiny_64x160'): (1.1e-2, 6e-3),
+    (torch.bfloat16, 'v6m_tiny_96x128'): (1.5e-1, 2.9e-1),
+}
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
 @pytest.mark.parametrize('case,weights,name', MODEL_CASES)
-def test_tiny_model_half_precision(case, weights, name, dtype, box_tol, prob_tol):
+def test_tiny_model_half_precision(case, weights, name, dtype):
     """fp16 / bf16 engines: activations and weights are rounded at every layer, so the stated tolerance is
     that of ~40 chained 11-bit / 8-bit roundings, not 1e-4."""
+    box_tol, prob_tol = HALF_TOL[(dtype, case)]
     g = load_golden(case)
     m = _tiny_model(name, weights, True).cuda().to(dtype)
     with torch.no_grad():
@@ -121,7 +133,8 @@ def test_p6_and_pan_models_match_reference_golden(case, name, build_kw, dtype):
         for i, f in enumerate(feats):
             assert rel_err(f.float().cpu(), g['neck%d' % i]) <= 1e-4
     else:
-        _check_pred(pred.cpu(), g['pred'], max(x.shape[2:]), 2e-2, 2e-2, 'f16 %s' % case)
+        # fp16: <= 3x measured (1.3e-3 of the extent on s6_tiny, 2.6e-3 in probability on s6pan_tiny)
+        _check_pred(pred.cpu(), g['pred'], max(x.shape[2:]), 4e-3, 8e-3, 'f16 %s' % case)
 
 
 def test_p6_engine_needs_multiples_of_64():
@@ -160,11 +173,118 @@ def test_full_model_fp16_vs_oracle_and_determinism():
         p1 = p1.clone()
         p2, _ = mh(x.cuda().half())
     assert torch.equal(p1, p2)                       # no atomics / split-K: bitwise reproducible
-    _check_pred(p1.cpu(), ref, 640, 2e-2, 3e-2, 'fp16 full yololps')
+    _check_pred(p1.cpu(), ref, 640, 2.4e-3, 9e-3, 'fp16 full yololps')       # <= 3x measured (7.7e-4 of the extent, 2.8e-3)
     # batch independence: image 1 alone gives the same rows as image 1 inside the batch
     with torch.no_grad():
         p3, _ = mh(x[1:2].cuda().half())
     assert torch.equal(p3[0], p1[1])
+
+
+def _prepared(name, dtype, sigma):
+    """The reference's inference preparation (inferer.py:25-68): float -> fuse_model -> switch_to_deploy -> half."""
+    from yolov6.utils.synth import build_synthetic
+    from yolov6.utils.torch_utils import fuse_model
+    from yolov6.layers.common import RepVGGBlock
+    m = build_synthetic(CFG(name), sigma=sigma)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = fuse_model(m).eval()
+    for layer in m.modules():
+        if isinstance(layer, RepVGGBlock):
+            layer.switch_to_deploy()
+    return m.cuda().to(dtype), sd
+
+
+def _batch_properties(m, x, conf, iou, max_det, probe):
+    """Size-independent properties of one batch through the engine (autotuned kernel variants): bitwise determinism,
+    image k of the batch == image k alone, lp_nms(engine pred) == the C oracle's NMS of that pred on the probed images."""
+    from oracle import lp_post
+    from yolov6.hip.runtime import nms_padded
+    with torch.no_grad():
+        p1 = m(x)[0].clone()
+        p2 = m(x)[0]
+        assert torch.equal(p1, p2)
+        for k in probe:
+            pk = m(x[k:k + 1])[0]
+            assert torch.equal(pk[0], p1[k]), k
+    assert torch.isfinite(p1).all()
+    sub = p1[probe].contiguous()
+    rows, keep, _ = lp_post.nms_c(sub.cpu().numpy(), conf, iou, max_det)
+    det, count, kept = nms_padded(p1.clone(), conf, iou, max_det, want_keep=True)
+    det, count, kept = det.cpu().numpy(), count.cpu().numpy(), kept.cpu().numpy()
+    assert sum(len(r) for r in rows) > 0
+    for i, k in enumerate(probe):
+        assert count[k] == len(rows[i])
+        assert np.array_equal(kept[k, :count[k]], keep[i]) and np.array_equal(det[k, :count[k]], rows[i])
+    return p1
+
+
+def test_config_yololpn_640_fp16_vs_oracle_and_bs128_properties():
+    """BASELINE configs[2]: yololpn 640x640 fp16 -- B=4 against the fp32 oracle, then the bs=128 batch through the
+    autotuned engine: determinism, batch independence, NMS == oracle NMS."""
+    from oracle import lp_oracle
+    m, sd = _prepared('yololpn', torch.float16, 0.6)
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(1234))
+    ref, _ = lp_oracle.forward(sd, lp_oracle.arch('yololpn'), x)
+    with torch.no_grad():
+        pred = m(x.cuda().half())[0]
+    # measured on MI355X (round 2, gpurun_out/parity.log): 5.8e-4 of the extent, 4.0e-3 in probability; tolerance = 3x that
+    _check_pred(pred.cpu(), ref, 640, 1.8e-3, 1.2e-2, 'fp16 full yololpn B4')
+    xb = torch.rand(128, 3, 640, 640, generator=torch.Generator().manual_seed(77)).cuda().half()
+    _batch_properties(m, xb, 0.4, 0.45, 1000, [0, 1, 63, 127])
+
+
+def test_config_yololps_640_fp16_bs32_properties():
+    """BASELINE configs[1] at its full batch: the autotuned variants the bench runs (B=32) keep determinism, batch
+    independence and NMS parity."""
+    m, _ = _prepared('yololps', torch.float16, 0.25)
+    xb = torch.rand(32, 3, 640, 640, generator=torch.Generator().manual_seed(1234)).cuda().half()
+    _batch_properties(m, xb, 0.4, 0.45, 1000, [0, 13, 31])
+
+
+def test_config_yolov6m_1280_bf16_vs_oracle_and_nms():
+    """BASELINE configs[4] per GPU: yolov6m 1280x1280 bf16 (DFL head, BottleRep residuals, N = 33600 anchors) against
+    the fp32 oracle, and lp_nms on that prediction against the C oracle."""
+    from oracle import lp_oracle, lp_post
+    from yolov6.hip.runtime import nms_padded
+    m, sd = _prepared('yolov6m', torch.bfloat16, 0.25)
+    x = torch.rand(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(5))
+    ref, _ = lp_oracle.forward(sd, lp_oracle.arch('yolov6m'), x)
+    with torch.no_grad():
+        pred = m(x.cuda().bfloat16())[0]
+        pred2 = m(torch.cat([x, x.flip(3)]).cuda().bfloat16())[0]
+    assert pred.shape == (1, 33600, 290) and torch.equal(pred2[0], pred[0])       # batch independence at B=2
+    # bf16 through ~90 chained layers: measured 5.8e-3 of the extent (7.4 px of |ref| up to 1467), 2.9e-2 in probability
+    # (gpurun_out/parity.log, round 2); stated tolerance = 3x that
+    _check_pred(pred.cpu(), ref, 1280, 1.8e-2, 9e-2, 'bf16 full yolov6m 1280 B1')
+    for conf, iou, max_det in ((0.4, 0.45, 1000), (0.03, 0.65, 300)):
+        rows, keep, _ = lp_post.nms_c(pred.cpu().numpy(), conf, iou, max_det)
+        det, count, kept = nms_padded(pred.clone(), conf, iou, max_det, want_keep=True)
+        n = int(count[0])
+        assert n == len(rows[0])
+        assert np.array_equal(kept[0, :n].cpu().numpy(), keep[0]) and np.array_equal(det[0, :n].cpu().numpy(), rows[0])
+
+
+def test_nms_more_than_max_nms_candidates():
+    """nms.py:115-116: more than 30000 rows pass the mask (reachable at 1280x1280, N = 33600, eval conf 0.03): only the
+    30000 best by score enter the greedy step.  Also the global-memory bitonic sort (> 8192 keys)."""
+    from oracle import lp_post
+    from yolov6.hip.runtime import nms_padded
+    pred = synth_pred(2, 33600, 31, frac_hot=1.0)
+    conf = 0.03
+    rows, keep, after = lp_post.nms_c(pred.numpy(), conf, 0.65, 300)
+    seg_max = torch.stack([pred[..., a:b].max(-1).values for a, b in zip((13, 44, 68, 105, 142, 179, 216, 216), (44, 68, 105, 142, 179, 216, 253, 253))], -1)
+    assert int(((seg_max.sum(-1) / 8.0) >= conf).sum(1).min()) > 30000          # the branch is really taken
+    det, count, kept = nms_padded(pred.clone().cuda(), conf, 0.65, 300, want_keep=True)
+    for b in range(2):
+        n = int(count[b])
+        assert n == len(rows[b]) == 300
+        assert np.array_equal(kept[b, :n].cpu().numpy(), keep[b]) and np.array_equal(det[b, :n].cpu().numpy(), rows[b])
+    # a selection that reaches the tail of the candidate list: a high IoU threshold keeps almost everything
+    rows, keep, _ = lp_post.nms_c(pred[:1].numpy(), conf, 0.99, 31000)
+    det, count, kept = nms_padded(pred[:1].clone().cuda(), conf, 0.99, 31000, want_keep=True)
+    n = int(count[0])
+    assert n == len(rows[0]) and n <= 30000
+    assert np.array_equal(kept[0, :n].cpu().numpy(), keep[0]) and np.array_equal(det[0, :n].cpu().numpy(), rows[0])
 
 
 def test_cuda_path_fails_loudly_without_extension(monkeypatch):
@@ -426,6 +546,26 @@ def test_rescale_round_matches_reference_formula():
         ref[:, :12] = Inferer.rescale(ori, ref[:, :12], tgt).round()
         got = rescale_round(ori, det.clone().cuda(), tgt).cpu()
         assert torch.equal(got, ref)
+
+
+def test_rescale_and_preprocess_kernels_match_the_reference_fixtures(golden):
+    """lp_rescale_round / lp_preprocess_letterbox against the fixtures captured from the reference's own Inferer statics
+    (tests/golden/make_golden_inferer.py): the rounded 12 coordinates bit for bit, the un-resized frames pixel for pixel."""
+    from yolov6.hip.runtime import rescale_round, preprocess_letterbox
+    z = golden('inferer_ref')
+    for k in range(int(z['rescale_n'])):
+        ori, tgt = tuple(z['rescale_%d_ori' % k].tolist()), tuple(z['rescale_%d_tgt' % k].tolist())
+        det = torch.zeros(z['rescale_%d_in' % k].shape[0], 28)
+        det[:, :12] = z['rescale_%d_in' % k]
+        det[:, 12:] = 0.25
+        got = rescale_round(ori, det.clone().cuda(), tgt).cpu()
+        assert torch.equal(got[:, :12], z['rescale_%d_round' % k]), k
+        assert torch.equal(got[:, 12:], det[:, 12:])
+    for k in range(int(z['pre_n'])):
+        frame = z['pre_%d_frame' % k].contiguous()
+        size, half = int(z['pre_%d_size' % k]), bool(int(z['pre_%d_half' % k]))
+        got = preprocess_letterbox(frame.cuda(), [size, size], 32, torch.float16 if half else torch.float32)
+        assert torch.equal(got.float().cpu(), z['pre_%d_out' % k]), k
 
 
 def test_graph_replay_matches_eager_launches():

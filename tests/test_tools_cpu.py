@@ -72,6 +72,32 @@ def test_rescale_and_box_convert():
     assert xywh.tolist() == [[20., 40., 20., 40.]]
 
 
+def test_inferer_statics_match_the_reference_fixtures(golden):
+    """Row a13: ``Inferer.rescale`` (+ ``.round()``), ``Inferer.precess_image`` and the letterbox geometry against
+    fixtures captured from the reference's own inferer.py (tests/golden/make_golden_inferer.py; cv2 absent there: frames
+    that need no resize are pinned pixel for pixel, resized frames by geometry only)."""
+    from yolov6.core.inferer import Inferer
+    from yolov6.data.data_augment import letterbox_geometry
+    z = golden('inferer_ref')
+    for k in range(int(z['rescale_n'])):
+        ori, tgt = tuple(z['rescale_%d_ori' % k].tolist()), tuple(z['rescale_%d_tgt' % k].tolist())
+        out = Inferer.rescale(ori, z['rescale_%d_in' % k].clone(), tgt)
+        assert torch.equal(out, z['rescale_%d_out' % k]), k
+        assert torch.equal(out.round(), z['rescale_%d_round' % k]), k
+    for k in range(int(z['pre_n'])):
+        frame = z['pre_%d_frame' % k].numpy()
+        size, half = int(z['pre_%d_size' % k]), bool(int(z['pre_%d_half' % k]))
+        img, src = Inferer.precess_image(frame, [size, size], 32, half)
+        assert img.dtype == (torch.float16 if half else torch.float32) and src is frame
+        assert torch.equal(img.float(), z['pre_%d_out' % k]), k
+    for k in range(int(z['geo_n'])):
+        h, w, size = z['geo_%d_in' % k].tolist()
+        r, new_unpad, (top, bottom, left, right), _ = letterbox_geometry((h, w), [size, size], stride=32)
+        assert list(new_unpad) == z['geo_%d_resized_wh' % k].tolist(), k
+        assert [new_unpad[1] + top + bottom, new_unpad[0] + left + right] == z['geo_%d_shape' % k].tolist(), k
+        assert [top, left, top + new_unpad[1], left + new_unpad[0]] == z['geo_%d_box' % k].tolist(), k
+
+
 def test_eval_speed_cli_cpu(workdir):
     sys.path.insert(0, os.path.join(REPO, 'tools'))
     import importlib
