@@ -43,8 +43,11 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
-    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'),
-                    help='per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run (tools/pmc_traffic.py)')
+    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'),
+                    help='per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run (tools/pmc_traffic.py); used only '
+                         'when the kernel-source hash recorded in it equals that of the sources this build was made from')
+    ap.add_argument('--profile-inner', type=int, default=4, help='back-to-back launches of each op per event pair in the per-op '
+                    'timing (amortises the cost of the event pair itself)')
     return ap.parse_args()
 
 
@@ -147,7 +150,9 @@ def main():
         pipe = InflightForward(model, depth)
     nstep = [0]
 
-    def step():
+    done_events = []        # when not None: one event per step, recorded on the post stream when the step's detections are complete
+
+    def step(pipe=None, depth=1):
         nonlocal gathered
         k = nstep[0] % depth
         nstep[0] += 1
@@ -166,8 +171,21 @@ def main():
             det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
             if world > 1:
                 gathered = gather_detections(det, count, out=gathered)
+            if done_events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(s_post)
+                done_events.append(ev)
+            if world > 1:
                 return gathered
         return det, count
+
+    def step_stats():
+        """Steady-state time per step from the completion events of consecutive steps: median and p10 / p90."""
+        ms = sorted(a_.elapsed_time(b_) for a_, b_ in zip(done_events[:-1], done_events[1:]))
+        if not ms:
+            return None
+        q = lambda f: round(ms[min(len(ms) - 1, int(f * len(ms)))], 4)   # noqa: E731
+        return {'median': q(0.5), 'p10': q(0.1), 'p90': q(0.9), 'n': len(ms)}
 
     def join():     # the measuring stream waits for everything enqueued on the other streams
         if pipe is not None:
@@ -176,38 +194,52 @@ def main():
         if s_post is not s_fwd:
             s_fwd.wait_stream(s_post)
 
-    with torch.no_grad():
-        for _ in range(depth):   # set-up, not steps of the measurement: every engine binds its arena and tunes its kernel variants
-            out = step()
+    def timed(pipe_, depth_):
+        """W untimed + K timed steps bracketed by barrier + synchronize on both sides: (seconds, host enqueue seconds, device ms)."""
+        nstep[0] = 0
+        for _ in range(depth_):  # set-up, not steps of the measurement: every engine binds its arena and tunes its kernel variants
+            out_ = step(pipe_, depth_)
         for _ in range(args.warmup):
-            out = step()
+            out_ = step(pipe_, depth_)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        del done_events[:]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for _ in range(args.steps):
-            out = step()
+            out_ = step(pipe_, depth_)
         join()
         ev1.record()
-        t_issue = time.perf_counter() - t0          # host time to enqueue all steps
+        t_issue_ = time.perf_counter() - t0         # host time to enqueue all steps
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        return time.perf_counter() - t0, t_issue_, ev0.elapsed_time(ev1), out_
+
+    with torch.no_grad():
+        elapsed, t_issue, dev_ms, out = timed(pipe, depth)
+        stats = step_stats()
+        # the same K steps with ONE batch in flight (a single engine; the NMS of a step still runs on the post stream under
+        # the next forward): what a caller gets who hands over one batch at a time
+        if depth > 1:
+            elapsed1, _, _, _ = timed(None, 1)
+            stats1 = step_stats()
+        else:
+            elapsed1, stats1 = elapsed, stats
+    el = torch.tensor([elapsed, elapsed1], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, elapsed1 = float(el[0].item()), float(el[1].item())
     counts = out[1].float().mean().item()
 
     result = None
     if rank == 0:
         # per-op device time (hipEvent pairs on torch's current stream, inside lp_engine_profile)
-        ops = eng.profile(x, reps=5)
+        ops = eng.profile(x, reps=5, inner=max(1, args.profile_inner))
         t_nms = []
         for _ in range(5):
             pred = eng.forward(x)
@@ -229,14 +261,21 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         total_ms = sum(o['ms'] for o in ops)
-        traffic = None
+        traffic, traffic_note = None, 'no PMC file for this workload'
         default_workload = (args.model, args.batch, args.size, args.dtype) == ('yololps', 32, 640, 'f16')
         if default_workload and os.path.exists(args.traffic_file):     # PMC counters come from a separate rocprofv3 pass
-            traffic = json.load(open(args.traffic_file)).get('hbm_bytes_per_launch')
+            from yolov6.hip.srchash import source_hash
+            tf = json.load(open(args.traffic_file))
+            if tf.get('kernel_source_hash') == source_hash():
+                traffic, traffic_note = tf.get('hbm_bytes_per_launch'), os.path.relpath(args.traffic_file, ROOT)
+            else:     # counters of another code state would go stale silently: report none
+                traffic_note = 'stale: %s was measured on kernel sources %s, this build is %s' % (
+                    os.path.relpath(args.traffic_file, ROOT), tf.get('kernel_source_hash'), source_hash())
         roofline = {
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': traffic,
-            'kernel': 'conv_mfma_kernel 3x3 (implicit GEMM, all %d launches of a step)' % len(conv3),
+            'traffic': traffic, 'traffic_source': traffic_note,
+            'kernel': '3x3 convolutions (conv3x3_pipe_kernel / conv_mfma_kernel<KS=3>, implicit GEMM, all %d launches of a step)' % len(conv3),
+            'timing': 'hipEvent pairs on the launch stream around %d back-to-back launches of each op' % max(1, args.profile_inner),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
             'algorithmic_bytes_per_launch': round(sum(o['bytes'] for o in conv3) / max(1, len(conv3))),
@@ -249,6 +288,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'value_inflight1': round(world * B * args.steps / elapsed1, 2),
+            'step_ms': stats, 'step_ms_inflight1': stats1,
             'config': {'workload': '%s %dx%d bs=%d/GPU %s, synthetic frames resident in HBM, seeded random-init weights '
                                    '(sigma %.2f), conf %.2f iou %.2f max_det %d'
                                    % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
@@ -257,7 +298,7 @@ def main():
                                    if depth > 1 else 'forward || NMS(+gather) of the previous step') if overlap else 'single stream',
                        'mean_detections_per_image': round(counts, 1),
                        'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),
-                       'device_ms_per_step': round(ev0.elapsed_time(ev1) / args.steps, 3)},
+                       'device_ms_per_step': round(dev_ms / args.steps, 3)},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -136,6 +136,9 @@ int lp_engine_num_ops(const lp_engine* e);
 int lp_engine_op_info(const lp_engine* e, int op, int* kind, int* ksize, int* cin, int* cout, double* flops,
                       double* bytes);
 int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps);
+/* Same, with `inner` back-to-back launches of every op between its two events (op_ms = event time / inner): the cost of
+ * the event pair itself is amortised, so op_ms approaches the kernel duration a rocprofv3 kernel trace reports. */
+int lp_engine_profile_ops(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps, int inner);
 
 /* Pick, per conv op and for the bound shape, the fastest of the kernel variants (workgroup tile / LDS ring depth)
  * that share the op's weight packing, by timing each in place (hipEvent pairs on `stream`).  The choice is

@@ -86,12 +86,12 @@ sys.path.insert(0, %r)
 from yolov6.core.sharded import gather_detections, shard_bounds, unpad
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'], rank=rank, world_size=world)
-B, max_det = 6, 5
+B, max_det = int(os.environ.get('LP_TEST_B', '6')), 5
 g = torch.Generator().manual_seed(0)
 det_full = torch.rand(B, max_det, 28, generator=g)
 cnt_full = torch.randint(0, max_det + 1, (B,), generator=g, dtype=torch.int32)
 lo, hi = shard_bounds(B, rank, world)
-det_all, cnt_all = gather_detections(det_full[lo:hi].clone(), cnt_full[lo:hi].clone())
+det_all, cnt_all = gather_detections(det_full[lo:hi].clone(), cnt_full[lo:hi].clone(), global_batch=B)
 assert torch.equal(det_all, det_full) and torch.equal(cnt_all, cnt_full), rank
 outs = unpad(det_all, cnt_all)
 assert [len(o) for o in outs] == cnt_full.tolist()
@@ -101,15 +101,44 @@ print('rank', rank, 'ok')
 '''
 
 
-def test_gather_detections_gloo_world2(tmp_path):
+@pytest.mark.parametrize('world,B', [(2, 6), (3, 7), (2, 1)], ids=['world2-even', 'world3-uneven', 'world2-empty-shard'])
+def test_gather_detections_gloo(tmp_path, world, B):
+    """The one exchange step of the sharded path over gloo: equal shards, shards that differ by one image (B % world != 0)
+    and a rank with an empty shard."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER % REPO)
-    port = str(29500 + os.getpid() % 2000)
+    port = str(29500 + (os.getpid() * 7 + world * 13 + B) % 2000)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=port, LP_TEST_B=str(B))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_engine_cache_stays_out_of_the_module_state():
+    """the cached engine must not ride along in ``Model.__dict__`` -- the reference's checkpoint format pickles
+    whole modules and EMA / get_model_info deep-copy them (checkpoint.py:22-32)."""
+    import copy
+    import io
+    import pickle
+    from yolov6.hip import runtime
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(os.path.join(REPO, 'configs', 'yololps.py'), width=0.0625)
+
+    class FakeEngine:                       # stands in for a built engine (no GPU here); real engines refuse pickling
+        def __reduce__(self):
+            raise TypeError('not picklable')
+    runtime._engines[m] = (('key',), FakeEngine())
+    assert '_lp_engine' not in m.__dict__
+    m2 = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save({'model': m, 'ema': None}, buf)
+    pickle.dumps(m)
+    assert m2 not in runtime._engines and m in runtime._engines
+    m.float()                                # Module._apply drops the stale engine
+    assert m not in runtime._engines
+    with pytest.raises(TypeError):
+        pickle.dumps(runtime.Engine.__new__(runtime.Engine))

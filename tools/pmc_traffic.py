@@ -3,7 +3,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3 --launches 47 > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --steps 3 --launches 47 > profiles/r02_pmc_traffic.json
 
 Counters are taken from the LAST steps*launches matching dispatches (the timed steps; earlier ones belong to warm-up
 and to the autotuner).  Corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB;
@@ -14,14 +14,20 @@ import argparse
 import csv
 import glob
 import json
+import os
 import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolov6.hip.srchash import source_hash   # noqa: E402
 
 
 def last_values(d, counter, n):
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     vals = []
     for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == counter and re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', r['Kernel_Name']):
+        k = r['Kernel_Name']
+        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k):
             vals.append(float(r['Counter_Value']))
     return vals[-n:]
 
@@ -37,7 +43,8 @@ fetch = last_values(a.fetch_dir, 'FETCH_SIZE', n)
 write = last_values(a.write_dir, 'WRITE_SIZE', n)
 fetch_b = sum(fetch) / len(fetch) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
 write_b = sum(write) / len(write) * 1024
-print(json.dumps({'kernel': 'conv_mfma_kernel 3x3', 'dispatches_averaged': len(fetch),
+print(json.dumps({'kernel': '3x3 conv launches (conv3x3_pipe_kernel + conv_mfma_kernel<KS=3>)', 'kernel_source_hash': source_hash(),
+                  'dispatches_averaged': len(fetch),
                   'fetch_bytes_per_launch': round(fetch_b), 'write_bytes_per_launch': round(write_b),
                   'hbm_bytes_per_launch': round(fetch_b + write_b),
                   'correction': 'FETCH_SIZE KiB x1024 x2 (gfx950 wide reads), WRITE_SIZE KiB x1024'}))

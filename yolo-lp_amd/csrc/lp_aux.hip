@@ -196,13 +196,13 @@ static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, i
         if ((cs / 8) % cand == 0 && need <= 64 * 1024 && (long long)B * (cs / 8 / cand) >= 512) { gp = cand; break; }
     }
     const size_t lds = (size_t)h * w * gp * 8 * sizeof(T) * 2;
-    if (lds > 128 * 1024 || h * w >= 65536) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
+    if (lds > POOL_MAX_LDS || h * w >= 65536) return fail(LP_ERR_UNSUPPORTED, "pool: feature map too large for the LDS-resident kernel");
     int gp_log2 = 0;
     while ((1 << gp_log2) < gp) ++gp_log2;
     const unsigned w_magic = (unsigned)(0x100000000ULL / (unsigned)w) + 1u;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)pool_chain_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool attr: ") + hipGetErrorString(e));
+        static std::atomic<unsigned long long> attr_done{0};   // one bit per device
+        if (int rc = set_max_lds_once(pool_chain_kernel<T>, (int)POOL_MAX_LDS, attr_done, "pool")) return rc;
     }
     hipLaunchKernelGGL((pool_chain_kernel<T>), dim3((unsigned)(B * (cs / 8 / gp))), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2,
                        (T*)d3, h, w, cs, gp_log2, w_magic);
@@ -210,6 +210,8 @@ static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, i
     if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool launch: ") + hipGetErrorString(e));
     return LP_OK;
 }
+
+size_t pool_min_lds_bytes(int dtype, int h, int w) { return (size_t)h * w * 8 * dtype_size(dtype) * 2; }
 
 int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B, int h, int w, int cs, hipStream_t st) {
     switch (dtype) {

@@ -99,6 +99,8 @@ struct lp_engine {
     };
     std::vector<CachedGraph> graphs;   // a few, so that alternating buffers do not re-capture (and destroy) every call
     unsigned long long graph_clock = 0;
+    hipStream_t last_stream = nullptr; // the caller's stream of the last forward (synchronised before the engine is destroyed)
+    bool last_stream_valid = false;
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
     unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
@@ -126,6 +128,12 @@ extern "C" int lp_engine_create(lp_engine** out, int act_dtype) {
 
 extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
+    // Nothing of the engine may die under in-flight work: the side lanes may still run kernels of the last forward that
+    // read launch arguments' device buffers and wait on / record the events destroyed below (an executable graph destroyed
+    // under its last launch aborted the process in round 1).  The caller's stream of the last forward is synchronised too.
+    for (int l = 1; l < LP_MAX_LANES; ++l)
+        if (e->lane_stream[l]) (void)hipStreamSynchronize(e->lane_stream[l]);
+    if (e->last_stream_valid) (void)hipStreamSynchronize(e->last_stream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (auto& g : e->graphs) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
@@ -502,6 +510,19 @@ static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>
     return off + 256;
 }
 
+// The SPPF pool chain keeps a whole h x w plane of a channel run in LDS twice (lp_aux.hip): stride-32 maps above 4096 px in
+// f16 / bf16 (inputs above ~2048x2048) and above 2048 px in f32 (~1440x1440) do not fit.  Checked when a shape is bound,
+// not when the first forward fails.
+static bool pool_fits(const lp_engine* e, int H, int W) {
+    for (const Op& op : e->ops) {
+        if (op.kind != OP_POOL) continue;
+        const Tensor& t = e->tensors[op.src[0]];
+        const int h = H >> t.sl, w = W >> t.sl;
+        if (pool_min_lds_bytes(e->dtype, h, w) > POOL_MAX_LDS || h * w >= 65536) return false;
+    }
+    return true;
+}
+
 // H and W must be multiples of the coarsest stride of the graph (32; 64 with a P6 level), at least 32
 static int size_granule(const lp_engine* e) {
     int sl = 5;
@@ -512,7 +533,7 @@ static int size_granule(const lp_engine* e) {
 extern "C" size_t lp_engine_arena_bytes(const lp_engine* e, int B, int H, int W) {
     if (!e || B < 1) return 0;
     const int g = size_granule(e);
-    if (H < g || W < g || H % g || W % g) return 0;
+    if (H < g || W < g || H % g || W % g || !pool_fits(e, H, W)) return 0;
     return place(e, B, H, W, nullptr);
 }
 
@@ -522,6 +543,9 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (B < 1 || H < gran || W < gran || H % gran || W % gran)
         return fail(LP_ERR_ARG, "lp_engine_bind: H and W must be positive multiples of " + std::to_string(gran) + " (the coarsest stride of the graph)");
     if (!dev_arena || ((uintptr_t)dev_arena & 255)) return fail(LP_ERR_ARG, "lp_engine_bind: need a 256-byte aligned device pointer");
+    if (!pool_fits(e, H, W))
+        return fail(LP_ERR_UNSUPPORTED, "lp_engine_bind: the SPPF pool chain keeps a whole stride-32 map in LDS: input too large (limit ~2048x2048 px in "
+                                        "f16 / bf16, ~1440x1440 in f32)");
     const size_t need = place(e, B, H, W, nullptr);
     if (bytes < need) return fail(LP_ERR_ARG, "lp_engine_bind: arena too small");
     if ((long long)B * H * W >= (1LL << 31)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_bind: batch too large for 32-bit pixel indices");
@@ -772,6 +796,8 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
     int rc = check_ready(e, x, x_dtype);
     if (rc) return rc;
     hipStream_t main_st = (hipStream_t)stream;
+    e->last_stream = main_st;
+    e->last_stream_valid = true;
     if (!e->use_graph) return issue_forward(e, x, x_dtype, pred, main_st);
     // hipGraph path: the ~80 launches (and the lane fork/join events) of one forward are captured once per
     // (input pointer, output pointer, dtype, launch geometry) and replayed with a single hipGraphLaunch -- what the
@@ -829,10 +855,11 @@ static int forward_single_lane(lp_engine* e, const void* x, int x_dtype, float* 
     return LP_OK;
 }
 
-extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps) {
+extern "C" int lp_engine_profile_ops(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps,
+                                     int inner) {
     int rc = check_ready(e, x, x_dtype);
     if (rc) return rc;
-    if (!op_ms || reps < 1) return fail(LP_ERR_ARG, "profile: op_ms / reps");
+    if (!op_ms || reps < 1 || inner < 1) return fail(LP_ERR_ARG, "profile: op_ms / reps / inner");
     hipStream_t st = (hipStream_t)stream;
     const size_t n = e->ops.size();
     while (e->events.size() < n + 1) {
@@ -846,18 +873,27 @@ extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float
     for (int r = 0; r < reps; ++r) {
         LP_HIP_CHECK(hipEventRecord(e->events[0], st));
         for (size_t i = 0; i < n; ++i) {
-            rc = run_op(e, i, x, x_dtype, pred, st);
-            if (rc) return rc;
+            // `inner` back-to-back launches of the op between two events: the event pair's own cost (a few microseconds of
+            // queue bubble) is spread over them, so the figure approaches the kernel's duration as a kernel trace reports it
+            // (the ops rewrite their own outputs with identical values)
+            for (int k = 0; k < inner; ++k) {
+                rc = run_op(e, i, x, x_dtype, pred, st);
+                if (rc) return rc;
+            }
             LP_HIP_CHECK(hipEventRecord(e->events[i + 1], st));
         }
         LP_HIP_CHECK(hipEventSynchronize(e->events[n]));
         for (size_t i = 0; i < n; ++i) {
             float ms = 0.f;
             LP_HIP_CHECK(hipEventElapsedTime(&ms, e->events[i], e->events[i + 1]));
-            op_ms[i] += ms / reps;
+            op_ms[i] += ms / reps / inner;
         }
     }
     return LP_OK;
+}
+
+extern "C" int lp_engine_profile(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, float* op_ms, int reps) {
+    return lp_engine_profile_ops(e, x, x_dtype, pred, stream, op_ms, reps, 1);
 }
 
 // Per-layer choice of the conv kernel variant for the bound shape: every variant that shares the op's weight

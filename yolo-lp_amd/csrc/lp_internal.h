@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/lp_hip.h"
@@ -21,6 +22,18 @@ int fail(int code, const std::string& msg);
         if (_e != hipSuccess)                                                                    \
             return ::lp::fail(LP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
+
+// Raise a kernel's dynamic-LDS limit (above the 64 KiB default) once PER DEVICE: the attribute belongs to the (function,
+// device) pair, and a process may drive several GPUs.  `done` is the caller's per-kernel-instantiation bit mask.
+template <typename K> inline int set_max_lds_once(K kernel, int bytes, std::atomic<unsigned long long>& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return LP_OK;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(LP_ERR_HIP, std::string(what) + ": LDS attribute: " + hipGetErrorString(e));
+    if (dev >= 0) done.fetch_or(1ull << dev, std::memory_order_release);
+    return LP_OK;
+}
 
 inline size_t dtype_size(int dt) { return dt == LP_F32 ? 4 : 2; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -98,6 +111,9 @@ int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
 int input_s2d_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);
+// LDS bytes the pool-chain kernel needs for an h x w plane (its narrowest channel run), and the limit it runs under.
+size_t pool_min_lds_bytes(int dtype, int h, int w);
+constexpr size_t POOL_MAX_LDS = 128 * 1024;
 int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B, int h, int w, int cs, hipStream_t st);
 
 }  // namespace lp

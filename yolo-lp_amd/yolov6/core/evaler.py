@@ -51,26 +51,41 @@ class Evaler:
         self.speed_result = torch.zeros(4, device=self.device)
         pred_results, total_targets = [], []
         vis_outputs, vis_imgs = [], None
+        on_gpu = self.device.type == 'cuda'
+        marks = []      # GPU: per batch four events on the current stream (pre | inference | NMS), read after the loop
         for i, (imgs, targets, paths, shapes) in enumerate(dataloader):
             c, h, w = imgs.shape[1:]
-            t1 = time_sync()
+            if on_gpu:   # a new batch shape binds + tunes the engine once: outside every timer
+                from yolov6.hip import runtime
+                runtime.prepare_for(model, imgs.shape, torch.float16 if self.half else torch.float32)
+            t1 = self._mark(on_gpu)
             imgs = imgs.to(self.device, non_blocking=True)
             imgs = imgs.half() if self.half else imgs.float()
             imgs /= 255
             batch_targets = self.split_targets(targets, imgs.shape[0], h, w)
-            self.speed_result[1] += time_sync() - t1
-            t2 = time_sync()
+            t2 = self._mark(on_gpu)
             outputs, _ = model(imgs)
-            self.speed_result[2] += time_sync() - t2
-            t3 = time_sync()
+            t3 = self._mark(on_gpu)
             outputs = non_max_suppression(outputs, self.conf_thres, self.iou_thres, multi_label=True)
-            self.speed_result[3] += time_sync() - t3
+            t4 = self._mark(on_gpu)
+            if on_gpu:
+                marks.append((t1, t2, t3, t4))
+            else:
+                self.speed_result[1] += t2 - t1
+                self.speed_result[2] += t3 - t2
+                self.speed_result[3] += t4 - t3
             self.speed_result[0] += len(outputs)
             pred_results.append(outputs)
             total_targets.append(batch_targets)
             if i == 0:
                 vis_num = min(len(imgs), 8)
                 vis_outputs, vis_imgs = outputs[:vis_num], imgs[:vis_num]
+        if marks:       # the reference's three buckets (evaler.py:104-140) as device time between HIP events: one sync in all
+            torch.cuda.synchronize(self.device)
+            for t1, t2, t3, t4 in marks:
+                self.speed_result[1] += t1.elapsed_time(t2) * 1e-3
+                self.speed_result[2] += t2.elapsed_time(t3) * 1e-3
+                self.speed_result[3] += t3.elapsed_time(t4) * 1e-3
         return pred_results, total_targets, vis_outputs, vis_imgs
 
     def split_targets(self, targets, batch, h, w):
@@ -98,6 +113,14 @@ class Evaler:
             LOGGER.warning('%d matched labels have IoU >= 1.0 and fit no IoU bin: skipped (the reference re-uses a stale bin '
                            'index for them)' % int(c[lp_metric.UNBINNED]))
         return lp_metric.finish(c)
+
+    def _mark(self, on_gpu):
+        """Bucket boundary: a HIP event recorded on the current stream (GPU) or the synchronised wall clock (CPU)."""
+        if not on_gpu:
+            return time_sync()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
 
     def eval_speed(self, task):
         """ms per image for pre-process / inference / NMS, like the reference's --task speed report."""

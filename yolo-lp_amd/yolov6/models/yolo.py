@@ -47,7 +47,8 @@ class Model(nn.Module):
         self = super()._apply(fn)
         self.detect.stride = fn(self.detect.stride)
         self.detect.grid = list(map(fn, self.detect.grid))
-        self.__dict__.pop('_lp_engine', None)   # weights moved / cast: the packed engine is stale
+        from yolov6.hip import runtime
+        runtime.drop_engine(self)               # weights moved / cast: the packed engine is stale
         return self
 
 

@@ -51,7 +51,8 @@ def fuse_model(model):
             m.conv = fuse_conv_and_bn(m.conv, m.bn)
             delattr(m, 'bn')
             m.forward = m.forward_fuse
-    model.__dict__.pop('_lp_engine', None)
+    from yolov6.hip import runtime
+    runtime.drop_engine(model)
     return model
 
 
