@@ -433,7 +433,7 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     base, tried = None, 0
-    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3)]:   # 32..34: LP_VARIANT_PIPE_*
+    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3)]:   # 32..35: LP_VARIANT_PIPE_*
         try:
             eng.set_variant(op, cfg, nb)
         except RuntimeError:
@@ -462,6 +462,8 @@ PIPE_CASES = [
     ([96], 192, 'relu', True, 13, 27, 5),
     ([64], 64, 'relu', True, 33, 17, 3),
     ([512], 512, 'relu', False, 20, 20, 2),
+    ([12], 32, 'relu', False, 96, 160, 3),           # the stem in its space-to-depth form: 32-cout packing, one K-chunk
+    ([16], 24, 'silu', False, 33, 47, 2),
 ]
 
 
@@ -501,7 +503,7 @@ def test_conv3x3_pipe(case, dtype):
         ref = q(ref) + 0.75 * q(res)
     assert rel_err(base.float().cpu(), ref) <= TOL[dtype]
     tried = 0
-    for cfg in (32, 33, 34):
+    for cfg in (32, 33, 34, 35):
         try:
             eng.set_variant(op, cfg, 3)
         except RuntimeError:

@@ -20,6 +20,7 @@ ap.add_argument('--k', type=int, default=3)
 ap.add_argument('--s', type=int, default=1)
 ap.add_argument('--hw', type=int, default=40, help='feature-map height = width at the conv input')
 ap.add_argument('--batch', type=int, default=32)
+ap.add_argument('--sl', type=int, default=5, help='log2 downscale of the conv input inside the dummy graph (lower it for big maps: the network input is hw << sl)')
 ap.add_argument('--iters', type=int, default=50)
 ap.add_argument('--dtype', default='f16')
 ap.add_argument('--variant', default='', help='force a kernel variant: cfg,nbuf (cfg 0..5 = tiles A..F, 16 / 17 = streaming 1x1 with 64 / 128 couts per wave)')
@@ -29,7 +30,7 @@ args = ap.parse_args()
 dt = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}[args.dtype]
 eng = Engine(dt, 'cuda:0')
 eng.autotune = False
-sl = 5
+sl = args.sl
 src = eng.tensor(args.cin, sl)
 g = torch.Generator().manual_seed(0)
 w = torch.randn(args.cout, args.cin, args.k, args.k, generator=g) * (2.0 / (args.cin * args.k * args.k)) ** 0.5

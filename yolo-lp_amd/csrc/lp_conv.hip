@@ -168,6 +168,7 @@ ConvShape conv_pipe_shape(int pcfg) {
     switch (pcfg) {
         case PIPE_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
         case PIPE_F: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
+        case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
     s.PB = 32 * s.WP * s.WGP;

@@ -1063,7 +1063,7 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
-    if (cfg >= LP_VARIANT_PIPE_D && cfg <= LP_VARIANT_PIPE_F) {
+    if (cfg >= LP_VARIANT_PIPE_D && cfg < LP_VARIANT_PIPE_D + PIPE_COUNT) {
         const int pc = cfg - LP_VARIANT_PIPE_D;
         if (!conv_pipe_fits(e->dtype, pc, cb, ks, stv, op.mode, op.nct, op.nphase) || op.kind != OP_CONV || nbuf != 3)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the pipelined 3x3 kernel does not fit this op");

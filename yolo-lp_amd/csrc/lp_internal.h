@@ -44,7 +44,7 @@ enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
 enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*64 x 128, 4 waves of 32x64*/, CFG_F = 5 /*128 x 128, 8 waves of 32x64*/, CFG_COUNT = 6 };
 
 // Pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc): workgroup configurations
-enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_COUNT = 3 };
+enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_COUNT = 4 };
 
 struct ConvSrc {
     const void* ptr;
