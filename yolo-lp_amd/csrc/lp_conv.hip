@@ -67,7 +67,10 @@ int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH
                             int pl = blk * 32 + lanes[k];
                             if (pl >= npix) pl = 0;
                             const int ty = pl / TW, tx = pl - ty * TW;
-                            const int hp = (ty * stride + t / ksize) * pitch + tx * stride + t % ksize;
+                            const int kx = t % ksize, hwe = (hw + 1) >> 1;
+                            // stride 2: rows are stored evens-first (lp_conv_kernel.inc), the walk over tx is dense
+                            const int col = stride == 2 ? (kx & 1) * hwe + tx + (kx >> 1) : tx * stride + kx;
+                            const int hp = (ty * stride + t / ksize) * pitch + col;
                             const int a = hp * rowb + swz_host(hp, half, gpr) * 16;
                             bool dup = false;
                             for (int m = 0; m < n; ++m) dup |= addr[m] == a;   // identical addresses broadcast
