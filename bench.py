@@ -40,6 +40,8 @@ def parse():
                     'second stream under the forward of step i+1)')
     ap.add_argument('--inflight', type=int, default=6, help='batches in flight on the GPU: consecutive steps run on this many '
                     'engines (arenas + streams), see yolov6/core/pipeline.py; 1 = one forward at a time')
+    ap.add_argument('--via-pred', action='store_true', help='Model.forward writes the [B,N,290] prediction tensor and lp_nms reads it back '
+                    '(the reference-shaped two-call path); default: the detections-only forward, whose head writes NMS candidates')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
@@ -150,25 +152,47 @@ def main():
         pipe = InflightForward(model, depth)
     nstep = [0]
 
+    ws1 = [[None, None], [None, None]]   # one-batch-in-flight path: two [candidate workspace, event of its last NMS], used alternately
     done_events = []        # when not None: one event per step, recorded on the post stream when the step's detections are complete
 
     def step(pipe=None, depth=1):
         nonlocal gathered
         k = nstep[0] % depth
         nstep[0] += 1
+        handle = release = None
         if pipe is not None:
-            pred, ready = pipe.submit(xs[k], fresh=False)      # the synthetic batches were made before the timed region
+            if args.via_pred:
+                pred, ready = pipe.submit(xs[k], fresh=False)      # the synthetic batches were made before the timed region
+                pred.record_stream(s_post)
+            else:
+                handle, ready, release = pipe.submit_det(xs[k], args.conf, fresh=False)
             s_post.wait_event(ready)
-            pred.record_stream(s_post)
         else:
-            pred = eng.forward(x)
+            if args.via_pred:
+                pred = eng.forward(x)
+            else:
+                slot = ws1[nstep[0] & 1]                          # two candidate workspaces: the NMS of step i runs under forward i + 1
+                if slot[0] is None:
+                    slot[0] = eng.det_workspace(B, args.size, args.size)
+                if slot[1] is not None:
+                    s_fwd.wait_event(slot[1])                    # the NMS that last read this workspace (two steps ago) is done
+                handle = eng.forward_det(x, args.conf, ws=slot[0])
             if overlap:
                 ready = torch.cuda.Event()
                 ready.record(s_fwd)
                 s_post.wait_event(ready)
-                pred.record_stream(s_post)
+                if args.via_pred:
+                    pred.record_stream(s_post)
         with torch.cuda.stream(s_post):
-            det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
+            if handle is None:
+                det, count, _ = runtime.nms_padded(pred, args.conf, args.iou, args.max_det)
+            else:
+                det, count, _ = runtime.nms_candidates(handle, args.iou, args.max_det)
+                if release is not None:
+                    release(s_post)
+                else:
+                    slot[1] = torch.cuda.Event()
+                    slot[1].record(s_post)
             if world > 1:
                 gathered = gather_detections(det, count, out=gathered)
             if done_events is not None:
@@ -294,6 +318,8 @@ def main():
                                    '(sigma %.2f), conf %.2f iou %.2f max_det %d'
                                    % (args.model, args.size, args.size, B, args.dtype, sigma, args.conf, args.iou, args.max_det),
                        'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
+                       'path': 'Model.forward -> pred[B,N,290] -> lp_nms' if args.via_pred else
+                               'detections-only forward (head writes NMS candidates: lp_engine_forward_det) -> lp_nms_candidates',
                        'streams': ('%d batches in flight (one engine + arena + streams each) || NMS(+gather) on a post stream' % depth
                                    if depth > 1 else 'forward || NMS(+gather) of the previous step') if overlap else 'single stream',
                        'mean_detections_per_image': round(counts, 1),

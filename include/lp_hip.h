@@ -124,6 +124,16 @@ int lp_engine_num_anchors(const lp_engine* e);
  * three neck maps) stays in the arena (lp_engine_tensor_info). */
 int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream);
 
+/* Detections-only forward for callers that go straight on to NMS (Inferer, Evaler.predict, the benchmark): the head does not
+ * write the [B,N,290] prediction tensor -- its class-predictor kernels apply non_max_suppression's candidate selection
+ * (nms.py:76-96: obj * cls, eight (max, first arg-max), the confidence mask, the score) to the sigmoids while they are still
+ * on chip and append the passing anchors to the candidate lists in `workspace` (lp_nms_workspace_bytes(B, N) bytes, 256-byte
+ * aligned).  lp_nms_candidates(workspace, ...) on the same stream finishes the job; det / count / keep are bit-identical to
+ * lp_nms on the prediction tensor lp_engine_forward would have written.  Replaces Model.forward + the first half of
+ * non_max_suppression (yolo.py:32-40, effidehead.py:283-301, nms.py:68-96). */
+int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, double conf_thres, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* enable != 0: lp_engine_forward captures its launches into a hipGraph on first use with a given (x, pred, dtype,
  * launch geometry) and replays it afterwards; any other pointers re-capture.  For launch-bound shapes (batch 1). */
 int lp_engine_set_graph(lp_engine* e, int enable);
@@ -173,6 +183,11 @@ int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src);
 size_t lp_nms_workspace_bytes(int B, int N);
 int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det, int32_t* count,
            int32_t* keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Second half of lp_nms for candidate lists already in `workspace` (written by lp_engine_forward_det): stable descending sort,
+ * the > 30000 cut (nms.py:115-116), greedy IoU suppression (torchvision.ops.nms), max_det (nms.py:121-125). */
+int lp_nms_candidates(int B, int N, double iou_thres, int max_det, float* det, int32_t* count, int32_t* keep, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Callers either side of the path.

@@ -362,6 +362,37 @@ def test_nms_on_engine_output_matches_oracle():
         assert np.array_equal(o.cpu().numpy(), r)
 
 
+@pytest.mark.parametrize('name,kw,B,H,W,dtype', [
+    ('yololps', dict(width=0.0625, sigma=1.5), 3, 128, 96, torch.float16),      # every level in the candidate-writing row kernel
+    ('yololps', dict(sigma=0.25), 4, 640, 640, torch.float16),                   # level 2 (256 channels) goes through the scratch + score_kernel
+    ('yololpn', dict(sigma=0.6), 5, 640, 416, torch.float16),
+    ('yolov6m', dict(width=0.125, sigma=1.5), 2, 160, 128, torch.bfloat16),      # DFL head
+    ('yololps', dict(width=0.125, sigma=1.5), 2, 256, 256, torch.float32),
+], ids=['lps-tiny', 'lps-full', 'lpn-full', 'v6m-dfl', 'lps-f32'])
+def test_detections_only_forward_matches_forward_plus_nms(name, kw, B, H, W, dtype):
+    """lp_engine_forward_det + lp_nms_candidates (the head writes NMS candidates, never the prediction tensor) == lp_nms on the
+    prediction tensor of lp_engine_forward: detections, counts and kept anchor indices bit for bit, for the inference and
+    the evaluation thresholds."""
+    from yolov6.hip import runtime
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG(name), **kw).cuda().to(dtype)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(11)).cuda().to(dtype)
+    with torch.no_grad():
+        pred = m(x)[0]
+    for conf, iou, max_det in ((0.4, 0.45, 1000), (0.03, 0.65, 300), (0.999, 0.5, 10)):
+        d0, c0, k0 = runtime.nms_padded(pred.clone(), conf, iou, max_det, want_keep=True)
+        for rep in range(2):
+            d1, c1, k1 = runtime.detect_padded(m, x, conf, iou, max_det, want_keep=True)
+            assert torch.equal(c1, c0), (conf, c0.tolist(), c1.tolist())
+            assert torch.equal(k1, k0) and torch.equal(d1, d0), conf
+    assert int(c0.sum()) == 0 or True
+    out = runtime.detect(m, x, 0.03, 0.65, 300)
+    ref = runtime.non_max_suppression(pred.clone(), 0.03, 0.65, 300)
+    assert sum(len(o) for o in ref) > 0
+    for o, r in zip(out, ref):
+        assert torch.equal(o, r)
+
+
 def test_nms_rejects_bad_arguments():
     from yolov6.utils.nms import non_max_suppression
     from yolov6.hip.runtime import nms_padded

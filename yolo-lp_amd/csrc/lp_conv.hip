@@ -2,6 +2,8 @@
 // The kernels themselves are in lp_conv_kernel.inc (one translation unit per activation dtype).
 #include "lp_internal.h"
 
+#include <cstdlib>
+
 namespace lp {
 
 int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
@@ -192,6 +194,9 @@ static int device_cus() {   // CUs of the current device = persistent workgroups
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         g_ncu[dev] = n / 8 * 8;
+        // LP_PIPE_MAXWG: cap of the persistent grid (experiments: with several batches in flight, kernels of different streams
+        // that each take part of the CUs overlap their prologues / epilogues with each other's main loops)
+        if (const char* cap = getenv("LP_PIPE_MAXWG")) { const int c = atoi(cap) / 8 * 8; if (c >= 8 && c < g_ncu[dev]) g_ncu[dev] = c; }
     }
     return g_ncu[dev];
 }
@@ -214,7 +219,7 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
 
 // Row-writer form of the class predictors (lp_head_rows.inc): whether the op fits, and the launch.
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c) {
-    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168;
+    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168 + 6 * 32 * 8 * 4 + 32 * 4;
     return nchunks >= 1 && nchunks <= 3 && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) && out_c == LP_PRED_COLS - 13;
 }
 

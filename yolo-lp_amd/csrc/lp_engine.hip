@@ -49,6 +49,7 @@ struct Op {
     int cfg = CFG_A, mode = MODE_ACT, nct = 1, nchunks = 0, nphase = 1, nbuf = 1, tile = 0;
     int stream_wc = 0, stream_rd = 2;   // stream_wc != 0: the streaming 1x1 kernel (2 or 4 cout tiles per wave) runs this op
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
+    size_t det_scratch = (size_t)-1;    // OP_HEAD_CLS whose detections-only form needs a prediction scratch: its arena offset (after bind)
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
@@ -495,8 +496,13 @@ extern "C" int lp_engine_upload(lp_engine* e, void* dev_weights, void* stream) {
     return LP_OK;
 }
 
+static bool rows_fits(const lp_engine* e, const Op& op);
+
 // ---- arena ----------------------------------------------------------------------------------------------
-static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>* out) {
+// Tensors back to back; behind them, for the detections-only forward, a prediction scratch [B][h*w][290] fp32 for every
+// pyramid level whose class predictors cannot run in the candidate-writing row kernel (too many input channels for its
+// resident weights): that level still goes through prediction rows, scored by score_kernel right after.
+static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>* out, std::vector<size_t>* scratch = nullptr) {
     size_t off = 0;
     const size_t esz = dtype_size(e->dtype);
     for (size_t i = 0; i < e->tensors.size(); ++i) {
@@ -506,6 +512,13 @@ static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>
         t.offset = off;
         if (!t.unused) off += ((size_t)B * t.h * t.w * t.cs * esz + 255) / 256 * 256;
         if (out) (*out)[i] = t;
+    }
+    if (scratch) scratch->assign(e->ops.size(), (size_t)-1);
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& op = e->ops[i];
+        if (op.kind != OP_HEAD_CLS || rows_fits(e, op)) continue;
+        if (scratch) (*scratch)[i] = off;
+        off += ((size_t)B * (H >> (3 + op.level)) * (W >> (3 + op.level)) * LP_PRED_COLS * 4 + 255) / 256 * 256;
     }
     return off + 256;
 }
@@ -549,7 +562,9 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     const size_t need = place(e, B, H, W, nullptr);
     if (bytes < need) return fail(LP_ERR_ARG, "lp_engine_bind: arena too small");
     if ((long long)B * H * W >= (1LL << 31)) return fail(LP_ERR_UNSUPPORTED, "lp_engine_bind: batch too large for 32-bit pixel indices");
-    place(e, B, H, W, &e->tensors);
+    std::vector<size_t> scratch;
+    place(e, B, H, W, &e->tensors, &scratch);
+    for (size_t i = 0; i < e->ops.size(); ++i) e->ops[i].det_scratch = scratch[i];
     e->arena = (char*)dev_arena;
     e->arena_bytes = bytes;
     e->B = B;
@@ -711,7 +726,47 @@ static int prepare_op(lp_engine* e, size_t idx) {
     return LP_OK;
 }
 
-static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* pred, hipStream_t st) {
+// Detections-only forward: where the head ops write instead of the prediction tensor.
+struct DetCtx {
+    NmsWs w;
+    float conf;
+};
+
+static int run_head_det(lp_engine* e, size_t idx, const DetCtx& dc, hipStream_t st) {
+    const Op& op = e->ops[idx];
+    const Launch& L = e->launches[idx];
+    const int dt = e->dtype;
+    ConvArgs a = L.a;
+    const int anchor0 = e->level_off[op.level], N = e->n_anchors;
+    if (L.mode == MODE_DECODE) {            // columns 0..11 of every anchor's candidate row
+        a.det_mode = 1;
+        a.out = dc.w.rows + (long long)anchor0 * LP_DET_COLS;
+        a.out_pix_stride = LP_DET_COLS;
+        a.out_img_stride = (long long)N * LP_DET_COLS;
+        return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
+    }
+    if (op.det_scratch == (size_t)-1) {     // class predictors + candidate selection in one kernel
+        a.det_mode = 1;
+        a.out = dc.w.rows;
+        a.det_keys = dc.w.keys;
+        a.det_cnt = dc.w.cnt;
+        a.det_np = dc.w.NP;
+        a.det_n = N;
+        a.det_anchor0 = anchor0;
+        a.det_conf = dc.conf;
+        return head_rows_launch(dt, a, L.cb_pack, st);
+    }
+    // this level's class predictors do not fit the row kernel: prediction rows in the scratch, scored right behind
+    float* const scratch = (float*)(e->arena + op.det_scratch);
+    const int rpi = a.Ho * a.Wo;
+    a.out = scratch + 13;
+    a.out_img_stride = (long long)rpi * LP_PRED_COLS;
+    int rc = conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
+    if (rc) return rc;
+    return nms_score_launch(scratch, e->B, rpi, anchor0, N, dc.conf, dc.w, false, st);
+}
+
+static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* pred, hipStream_t st, const DetCtx* det = nullptr) {
     const Op& op = e->ops[idx];
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
@@ -726,6 +781,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     if (L.mode == MODE_ACT && L.pipe) return conv_pipe_launch(dt, L.pipe - 1, L.a, st);
     if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.a, L.cb_pack, st);
     if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
+    if (det) return run_head_det(e, idx, *det, st);
     if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
     ConvArgs a = L.a;
     a.out = pred + L.pred_off;
@@ -754,11 +810,11 @@ static int ensure_lanes(lp_engine* e) {
     return LP_OK;
 }
 
-static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t main_st) {
+static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t main_st, const DetCtx* det = nullptr) {
     int rc;
     if (e->n_lanes <= 1) {
         for (size_t i = 0; i < e->ops.size(); ++i) {
-            rc = run_op(e, i, x, x_dtype, pred, main_st);
+            rc = run_op(e, i, x, x_dtype, pred, main_st, det);
             if (rc) return rc;
         }
         return LP_OK;
@@ -775,7 +831,7 @@ static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, 
         const Op& op = e->ops[i];
         hipStream_t st = e->lane_stream[op.lane];
         for (int d : op.deps) LP_HIP_CHECK(hipStreamWaitEvent(st, e->op_event[d], 0));
-        rc = run_op(e, i, x, x_dtype, pred, st);
+        rc = run_op(e, i, x, x_dtype, pred, st, det);
         if (rc) return rc;
         if (op.signal) LP_HIP_CHECK(hipEventRecord(e->op_event[i], st));
     }
@@ -845,6 +901,24 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
     hit->stream = main_st;
     hit->last_use = ++e->graph_clock;
     return LP_OK;
+}
+
+extern "C" int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, double conf_thres, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(LP_ERR_ARG, "lp_engine_forward_det: need a 256-byte aligned workspace");
+    if (!(conf_thres >= 0.0 && conf_thres <= 1.0)) return fail(LP_ERR_ARG, "lp_engine_forward_det: conf_thres must be in [0, 1]");
+    DetCtx dc;
+    dc.w = nms_carve(workspace, e->B, e->n_anchors);
+    dc.conf = (float)conf_thres;
+    if (workspace_bytes < dc.w.bytes) return fail(LP_ERR_ARG, "lp_engine_forward_det: workspace too small (lp_nms_workspace_bytes)");
+    hipStream_t main_st = (hipStream_t)stream;
+    e->last_stream = main_st;
+    e->last_stream_valid = true;
+    // the candidate counters are zeroed on the caller's stream BEFORE the lanes fork: every head op comes behind it
+    LP_HIP_CHECK(hipMemsetAsync(dc.w.cnt, 0, (size_t)e->B * 4, main_st));
+    return issue_forward(e, x, x_dtype, nullptr, main_st, &dc);
 }
 
 static int forward_single_lane(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t st) {

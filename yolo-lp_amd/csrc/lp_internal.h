@@ -77,6 +77,15 @@ struct ConvArgs {
     int nphase;
     long long w_phase_stride;  // elements
     int act;
+    // detections-only forward (lp_engine_forward_det): the head writes NMS candidates instead of the prediction tensor.
+    //   MODE_DECODE with det_mode: out = candidate rows [B][N][28], columns 0..11 (xyxy + corners) of EVERY anchor;
+    //   head_cls_rows_kernel<.., true>: out = candidate rows (columns 12..27 of the anchors that pass the confidence mask),
+    //   det_keys [B][det_np] / det_cnt [B] = the candidate lists lp_nms_candidates sorts.
+    int det_mode;
+    unsigned long long* det_keys;
+    int* det_cnt;
+    int det_np, det_n, det_anchor0;   // keys per image (power of two), anchors per image, first anchor of this level
+    float det_conf;
     // MODE_DECODE
     int reg_bins;
     const float* proj;
@@ -106,7 +115,22 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st);
 
 // Row-writer form of the class predictors (lp_head_rows.inc).
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c);
-int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);   // a.det_mode: the candidate-writing form
+
+// ---- post-processing pieces shared with the engine's detections-only forward (lp_nms.hip) ----
+struct NmsWs {  // carve-up of the caller's NMS workspace
+    int32_t* cnt;              // [B]
+    unsigned long long* keys;  // [B][NP]
+    float* rows;               // [B][N][28]
+    float4* sbox;              // [B][N]
+    int32_t* kept;             // [B][N]
+    int NP;
+    size_t bytes;
+};
+NmsWs nms_carve(void* base, int B, int N);
+// score_kernel over `rows_per_img` prediction rows per image (row stride 290 floats, images `rows_per_img` rows apart) whose
+// anchors are anchor0.. of N: appends the candidates; write_box false leaves columns 0..11 of the candidate rows alone.
+int nms_score_launch(float* pred, int B, int rows_per_img, int anchor0, int N, float conf_f, const NmsWs& w, bool write_box, hipStream_t st);
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);

@@ -13,6 +13,7 @@
 //   order: descending score, ties by ascending anchor index (stable sort); at most 30000 candidates
 //   greedy: keep i, suppress later j with inter/(area_i+area_j-inter) > iou (double compare), until max_det
 #include "lp_internal.h"
+#include "lp_score.inc"
 
 namespace lp {
 
@@ -20,25 +21,13 @@ static constexpr int NCOL = LP_PRED_COLS;
 static constexpr int NDET = LP_DET_COLS;
 static constexpr int MAX_NMS = 30000;
 static constexpr int SORT_LDS_KEYS = 8192;   // keys sorted inside LDS (64 KiB); larger lists are sorted in global memory
-__constant__ int c_seg[9] = {13, 44, 68, 105, 142, 179, 216, 253, 290};
-
-struct NmsWs {  // carve-up of the caller's workspace
-    int32_t* cnt;            // [B]
-    unsigned long long* keys;  // [B][NP]
-    float* rows;             // [B][N][28]
-    float4* sbox;            // [B][N]
-    int32_t* kept;           // [B][N]
-    int NP;
-    size_t bytes;
-};
-
 static int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
     return p;
 }
 
-static NmsWs carve(void* base, int B, int N) {
+NmsWs nms_carve(void* base, int B, int N) {
     NmsWs w;
     w.NP = next_pow2(N < 64 ? 64 : N);
     size_t off = 0;
@@ -56,27 +45,19 @@ static NmsWs carve(void* base, int B, int N) {
     return w;
 }
 
-// (value, index) max with torch.max's tie rule: the smaller index wins among equal values.
-__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
-
-// Rotate-within-16-lanes DPP move (row_ror:n): lane j of each 16-lane row receives lane (j - n) mod 16.
-template <int N> __device__ __forceinline__ float ror16f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
-}
-template <int N> __device__ __forceinline__ int ror16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
-
 // 16 lanes per anchor row, 4 rows per wave, 16 rows per block iteration.  Lane j of a row group owns columns
 // j, j+16, ...: it folds its own columns of each head in ascending order (first maximum wins), then four
 // rotate steps (1,2,4,8) of a (value, index) max-combine leave every lane of the group with the head's result
 // (the combine is commutative, associative and idempotent, so a rotate all-reduce is exact).
-__global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, int B, int N, float conf_f,
+// The rows may be one pyramid level of the anchors only (detections-only forward, levels whose class predictors still go
+// through a prediction scratch): RPI prediction rows per image = anchors anchor0 .. anchor0 + RPI of the N per image;
+// write_box false leaves columns 0..11 of the candidate rows to the decode kernel that has written them already.
+__global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, int B, int RPI, int anchor0, int N, float conf_f,
                                                    float* __restrict__ rows, unsigned long long* __restrict__ keys,
-                                                   int32_t* __restrict__ cnt, int NP) {
+                                                   int32_t* __restrict__ cnt, int NP, int write_box) {
     constexpr int NK = (NCOL + 15) / 16;   // 19 column slots per lane
     const int j = threadIdx.x & 15;
-    const long long nrows = (long long)B * N;
+    const long long nrows = (long long)B * RPI;
     const long long gstride = (long long)gridDim.x * 16;
     for (long long base = (long long)blockIdx.x * 16; base < nrows; base += gstride) {   // block-uniform trip count
         const long long row0 = base + (threadIdx.x >> 4);
@@ -89,7 +70,7 @@ __global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, in
             const int c = j + 16 * k;
             v[k] = c < NCOL ? x[c] : 0.f;
         }
-        const float obj = __shfl(v[0], 4, 16);
+        const float obj = write_box ? __shfl(v[0], 4, 16) : 1.0f;   // (detections-only levels: the decode kernel does not fill the scratch; obj is 1)
         // conf = obj_conf * cls_conf, in place (nms.py:76); obj == 1 leaves the bits unchanged: no store needed
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -101,30 +82,10 @@ __global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, in
         }
         float cf[8];
         int ci[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            constexpr int SEGS[9] = {13, 44, 68, 105, 142, 179, 216, 253, 290};
-            const int a = SEGS[s], b = SEGS[s + 1];
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                if (16 * k + 15 < a || 16 * k >= b) continue;            // compile-time: slot k cannot touch head s
-                const int c = j + 16 * k;
-                if (c >= a && c < b && v[k] > bv) { bv = v[k]; bi = c - a; }   // ascending columns: first maximum stays
-            }
-            { const float ov = ror16f<1>(bv); const int oi = ror16i<1>(bi); argmax_combine(bv, bi, ov, oi); }
-            { const float ov = ror16f<2>(bv); const int oi = ror16i<2>(bi); argmax_combine(bv, bi, ov, oi); }
-            { const float ov = ror16f<4>(bv); const int oi = ror16i<4>(bi); argmax_combine(bv, bi, ov, oi); }
-            { const float ov = ror16f<8>(bv); const int oi = ror16i<8>(bi); argmax_combine(bv, bi, ov, oi); }
-            cf[s] = bv;
-            ci[s] = bi;
-        }
-        float m = cf[0] + cf[1]; m = m + cf[2]; m = m + cf[3]; m = m + cf[4]; m = m + cf[5];
-        m = m + cf[6]; m = m + cf[6]; m = m / 8.0f;
+        score_heads<0, NK>(v, j, cf, ci);
+        const float m = score_mask_value(cf);
         const bool pass = live && (m >= conf_f);        // uniform inside a 16-lane group
-        float sc = cf[0] + cf[1]; sc = sc + cf[2]; sc = sc + cf[3]; sc = sc + cf[4]; sc = sc + cf[5];
-        sc = sc + cf[6]; sc = sc + cf[7]; sc = sc / 8.0f;
+        const float sc = score_value(cf);
 
         // all lanes take part in the shuffles; only passing groups store
         const float cx = __shfl(v[0], 0, 16), cy = __shfl(v[0], 1, 16), bw = __shfl(v[0], 2, 16), bh = __shfl(v[0], 3, 16);
@@ -145,16 +106,13 @@ __global__ __launch_bounds__(256) void score_kernel(float* __restrict__ pred, in
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (j == 4 + k) o1 = (float)ci[k];
-            float* out = rows + row * NDET;
-            out[j] = o0;
+            const int bimg = (int)(row / RPI), n = anchor0 + (int)(row - (long long)bimg * RPI);
+            float* out = rows + ((long long)bimg * N + n) * NDET;
+            if (write_box || j >= 12) out[j] = o0;
             if (j < 12) out[16 + j] = o1;
             if (j == 0) {
-                const int bimg = (int)(row / N), n = (int)(row - (long long)bimg * N);
-                unsigned u = __float_as_uint(sc);
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable bits
-                const unsigned long long key = ((unsigned long long)(~u) << 32) | (unsigned)n;  // descending score, then index
                 const int pos = atomicAdd(&cnt[bimg], 1);
-                keys[(long long)bimg * NP + pos] = key;
+                keys[(long long)bimg * NP + pos] = score_key(sc, n);
             }
         }
     }
@@ -300,9 +258,21 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
 
 using namespace lp;
 
+namespace lp {
+int nms_score_launch(float* pred, int B, int rows_per_img, int anchor0, int N, float conf_f, const NmsWs& w, bool write_box, hipStream_t st) {
+    const long long nrows = (long long)B * rows_per_img;
+    long long blocks = (nrows + 15) / 16;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, B, rows_per_img, anchor0, N, conf_f, w.rows, w.keys,
+                       w.cnt, w.NP, write_box ? 1 : 0);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
+}
+}  // namespace lp
+
 extern "C" size_t lp_nms_workspace_bytes(int B, int N) {
     if (B < 1 || N < 1) return 256;
-    return carve(nullptr, B, N).bytes;
+    return nms_carve(nullptr, B, N).bytes;
 }
 
 extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det,
@@ -312,7 +282,7 @@ extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_t
     if (!(conf_thres >= 0.0 && conf_thres <= 1.0) || !(iou_thres >= 0.0 && iou_thres <= 1.0))
         return fail(LP_ERR_ARG, "lp_nms: thresholds must be in [0, 1]");
     if (((uintptr_t)workspace & 255) != 0) return fail(LP_ERR_ARG, "lp_nms: workspace must be 256-byte aligned");
-    NmsWs w = carve(workspace, B, N);
+    NmsWs w = nms_carve(workspace, B, N);
     if (workspace_bytes < w.bytes) return fail(LP_ERR_ARG, "lp_nms: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const float conf_f = (float)conf_thres;
@@ -320,10 +290,25 @@ extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_t
     if ((double)thr_f > iou_thres) thr_f = nextafterf(thr_f, -INFINITY);
 
     LP_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st));
-    const long long nrows = (long long)B * N;
-    long long blocks = (nrows + 15) / 16;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, B, N, conf_f, w.rows, w.keys, w.cnt, w.NP);
+    if (int rc = nms_score_launch(pred, B, N, 0, N, conf_f, w, true, st)) return rc;
+    hipLaunchKernelGGL(sort_kernel, dim3((unsigned)B), dim3(1024), 0, st, w.keys, w.cnt, w.NP);
+    hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)B), dim3(NMS_T), 0, st, w.keys, w.rows, w.sbox, w.kept, w.cnt, N, w.NP,
+                       thr_f, max_det, det, count, keep);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
+}
+
+extern "C" int lp_nms_candidates(int B, int N, double iou_thres, int max_det, float* det, int32_t* count, int32_t* keep,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!det || !count || !workspace) return fail(LP_ERR_ARG, "lp_nms_candidates: null pointer");
+    if (B < 1 || N < 1 || max_det < 1) return fail(LP_ERR_ARG, "lp_nms_candidates: B, N and max_det must be positive");
+    if (!(iou_thres >= 0.0 && iou_thres <= 1.0)) return fail(LP_ERR_ARG, "lp_nms_candidates: threshold must be in [0, 1]");
+    if (((uintptr_t)workspace & 255) != 0) return fail(LP_ERR_ARG, "lp_nms_candidates: workspace must be 256-byte aligned");
+    NmsWs w = nms_carve(workspace, B, N);
+    if (workspace_bytes < w.bytes) return fail(LP_ERR_ARG, "lp_nms_candidates: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float thr_f = (float)iou_thres;                       // largest fp32 not above the double threshold
+    if ((double)thr_f > iou_thres) thr_f = nextafterf(thr_f, -INFINITY);
     hipLaunchKernelGGL(sort_kernel, dim3((unsigned)B), dim3(1024), 0, st, w.keys, w.cnt, w.NP);
     hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)B), dim3(NMS_T), 0, st, w.keys, w.rows, w.sbox, w.kept, w.cnt, N, w.NP,
                        thr_f, max_det, det, count, keep);

@@ -27,6 +27,8 @@ class InflightForward:
             self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
         torch.cuda.synchronize(self.device)     # the engines' packed weights are uploaded before any side stream uses them
         self._next = 0
+        self._ws = [None] * self.depth          # detections-only path: one NMS workspace per engine ...
+        self._ws_free = [None] * self.depth     # ... and the event after which its previous candidates are no longer needed
 
     def submit(self, x, fresh=True):
         """Enqueue the forward of batch ``x`` on the next engine; returns (pred, event): ``pred`` [B,N,290] fp32 is
@@ -47,3 +49,33 @@ class InflightForward:
             done.record(s)
         x.record_stream(s)
         return pred, done
+
+    def submit_det(self, x, conf_thres, fresh=True):
+        """Detections-only form of ``submit``: the forward of batch ``x`` writes NMS candidates (``Engine.forward_det``) into the
+        slot's own workspace; returns (handle, event, release): run ``runtime.nms_candidates(handle, ...)`` on a stream that
+        waits for ``event``, then call ``release(stream)`` so that the slot's next forward waits for that NMS."""
+        k = self._next
+        self._next = (k + 1) % self.depth
+        s = self.streams[k]
+        eng = self.engines[k]
+        shape = (x.shape[0], x.shape[2], x.shape[3])
+        if k and shape not in eng.tuned and shape in self.engines[0].tuned:
+            eng.copy_tuning(self.engines[0])
+        if fresh:
+            s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            if self._ws[k] is None or eng.bound != shape:
+                self._ws[k] = eng.det_workspace(*shape)
+                self._ws_free[k] = None
+            if self._ws_free[k] is not None:
+                s.wait_event(self._ws_free[k])          # the NMS of this slot's previous batch has read its candidates
+            handle = eng.forward_det(x, conf_thres, ws=self._ws[k])
+            done = torch.cuda.Event()
+            done.record(s)
+        x.record_stream(s)
+
+        def release(stream):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._ws_free[k] = ev
+        return handle, done, release

@@ -52,6 +52,8 @@ SYMBOLS = {
     'lp_engine_num_ops': (c_int, [c_void_p]),
     'lp_engine_op_info': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_double), POINTER(c_double)]),
+    'lp_engine_forward_det': (c_int, [c_void_p, c_void_p, c_int, ctypes.c_double, c_void_p, c_size_t, c_void_p]),
+    'lp_nms_candidates': (c_int, [c_int, c_int, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'lp_engine_profile': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int]),
     'lp_engine_profile_ops': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_int, c_int]),
     'lp_engine_autotune': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),

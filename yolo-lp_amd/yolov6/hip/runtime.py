@@ -403,6 +403,48 @@ class Engine:
                                                  ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
         return pred
 
+    def forward_det(self, x, conf_thres, ws=None):
+        """Detections-only forward (lp_engine_forward_det) on the current stream: the head writes NMS candidates into the
+        workspace instead of the [B,N,290] prediction tensor.  Returns the handle ``nms_candidates`` takes: (workspace tensor,
+        B, N).  ``ws``: a workspace to reuse (the caller orders its previous use before this call); by default the
+        workspace of the current (device, stream)."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected [B,3,H,W], got %s' % (tuple(x.shape),))
+        if x.dtype not in _DT:
+            raise TypeError('unsupported input dtype %s' % x.dtype)
+        if not 0.0 <= conf_thres <= 1.0:
+            raise ValueError('conf_thres must be in [0, 1]')
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        with torch.cuda.device(self.device):
+            if self.autotune and (B, H, W) not in self.tuned and len(self.tuned) < self.max_tuned_shapes:
+                self.forward(x)                                 # first batch of this shape: bind + tune through the plain forward
+            self.bind(B, H, W)
+            N = self.n_anchors
+            need = self.lib.lp_nms_workspace_bytes(B, N)
+            if ws is None:
+                key = (self.device, torch.cuda.current_stream(self.device).cuda_stream)
+                ws = _nms_ws.get(key)
+                if ws is None or ws.numel() < need + 256:
+                    ws = _nms_ws[key] = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            elif ws.numel() < need + 256:
+                raise ValueError('workspace too small: %d bytes needed' % (need + 256))
+            wsp = ctypes.c_void_p((ws.data_ptr() + 255) // 256 * 256)
+            abi.check(self.lib.lp_engine_forward_det(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype], float(conf_thres), wsp, need,
+                                                     self._stream()), 'lp_engine_forward_det')
+        return ws, B, N
+
+    def det_workspace(self, B, H, W):
+        """A private workspace for ``forward_det`` on this engine (several batches in flight: one per engine)."""
+        with torch.cuda.device(self.device):
+            self.bind(B, H, W)
+            return torch.empty(self.lib.lp_nms_workspace_bytes(B, self.n_anchors) + 256, dtype=torch.uint8, device=self.device)
+
+    def detect(self, x, conf_thres, iou_thres, max_det, want_keep=False):
+        """Detections-only forward + NMS (lp_engine_forward_det + lp_nms_candidates): (det[B,max_det,28], count[B] int32, keep or
+        None), bit-identical to ``nms_padded(self.forward(x), ...)`` without the [B,N,290] prediction tensor ever being written."""
+        return nms_candidates(self.forward_det(x, conf_thres), iou_thres, max_det, want_keep)
+
     def profile(self, x, reps=3, inner=1):
         """Per-op device milliseconds (hipEvent pairs around ``inner`` back-to-back launches of each op) + op descriptions,
         for bench.py."""
@@ -478,6 +520,38 @@ def model_forward(model, x):
         eng.set_graph(getattr(model, 'lp_graph', False))
     pred = eng.forward(x)
     return [pred, [eng.tensor_view(t) for t in eng.neck_ids]]
+
+
+def nms_candidates(handle, iou_thres, max_det, want_keep=False):
+    """Second half of the NMS (lp_nms_candidates: sort, > 30000 cut, greedy suppression, max_det) on the current stream for the
+    candidate lists ``Engine.forward_det`` left in its workspace: (det[B,max_det,28], count[B] int32, keep or None)."""
+    ws, B, N = handle
+    if not 0.0 <= iou_thres <= 1.0:
+        raise ValueError('iou_thres must be in [0, 1]')
+    lib = abi.load()
+    dev = ws.device
+    with torch.cuda.device(dev):
+        need = lib.lp_nms_workspace_bytes(B, N)
+        det = torch.empty(B, max_det, abi.LP_DET_COLS, dtype=torch.float32, device=dev)
+        count = torch.empty(B, dtype=torch.int32, device=dev)
+        keep = torch.empty(B, max_det, dtype=torch.int32, device=dev) if want_keep else None
+        abi.check(lib.lp_nms_candidates(B, N, float(iou_thres), int(max_det), ctypes.c_void_p(det.data_ptr()),
+                                        ctypes.c_void_p(count.data_ptr()), ctypes.c_void_p(keep.data_ptr()) if want_keep else None,
+                                        ctypes.c_void_p((ws.data_ptr() + 255) // 256 * 256), need,
+                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'lp_nms_candidates')
+    return det, count, keep
+
+
+def detect_padded(model, x, conf_thres, iou_thres, max_det, want_keep=False):
+    """``Model.forward`` + ``non_max_suppression`` of a GPU model as one call that never materialises the prediction tensor:
+    (det[B,max_det,28], count[B], keep or None).  For callers that only want detections (Inferer, Evaler.predict, bench.py)."""
+    return engine_for(model).detect(x, conf_thres, iou_thres, max_det, want_keep)
+
+
+def detect(model, x, conf_thres, iou_thres, max_det):
+    """Reference-shaped result of ``non_max_suppression(model(x)[0], ...)``: list (len B) of [n_i, 28] tensors."""
+    det, count, _ = detect_padded(model, x, conf_thres, iou_thres, max_det)
+    return [det[b, :n] for b, n in enumerate(count.cpu().tolist())]
 
 
 # ---------------------------------------------------------------------------------------------------
