@@ -219,7 +219,7 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
 
 // Row-writer form of the class predictors (lp_head_rows.inc): whether the op fits, and the launch.
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c) {
-    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168 + 6 * 32 * 8 * 4 + 32 * 4;
+    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168 + 6 * 32 * 8 * 4 + 32 * 4 + 32 * 8 * 4;
     return nchunks >= 1 && nchunks <= 3 && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) && out_c == LP_PRED_COLS - 13;
 }
 
