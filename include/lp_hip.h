@@ -175,7 +175,7 @@ int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src);
  *   pred      device fp32 [B,N,290]; columns 13.. are multiplied by column 4 IN PLACE (nms.py:76)
  *   conf/iou  thresholds as the python floats the reference receives (conf is compared in fp32, iou in
  *             double, as torch / torchvision do)
- *   det       device fp32 [B,max_det,28], rows in descending-score order; rows >= count[b] are zero
+ *   det       device fp32 [B,max_det,28] (16-byte aligned), rows in descending-score order; rows >= count[b] are zero
  *   count     device int32 [B]
  *   keep      device int32 [B,max_det] anchor index of every kept row, or NULL
  *   workspace device scratch of at least lp_nms_workspace_bytes(B,N) bytes

@@ -266,7 +266,7 @@ def test_config_yolov6m_1280_bf16_vs_oracle_and_nms():
 
 def test_nms_more_than_max_nms_candidates():
     """nms.py:115-116: more than 30000 rows pass the mask (reachable at 1280x1280, N = 33600, eval conf 0.03): only the
-    30000 best by score enter the greedy step.  Also the global-memory bitonic sort (> 8192 keys)."""
+    30000 best by score enter the greedy step.  Also the sort of a list longer than one LDS block (65 536 slots: four blocks)."""
     from oracle import lp_post
     from yolov6.hip.runtime import nms_padded
     pred = synth_pred(2, 33600, 31, frac_hot=1.0)
@@ -320,7 +320,9 @@ def test_nms_golden_bit_exact(case):
     (2, 8400, 22, 0.30, 0.03, 0.65, 300, True),        # eval defaults: every anchor is a candidate
     (3, 2100, 23, 0.50, 0.25, 0.50, 50, False),        # obj != 1, truncation by max_det
     (1, 33600, 24, 0.02, 0.4, 0.45, 1000, True),       # 1280x1280 anchor count
-    (2, 77, 25, 1.00, 0.30, 0.10, 1000, True),         # fewer anchors than a wave
+    (2, 77, 25, 1.00, 0.30, 0.10, 1000, True),         # fewer anchors than a wave; score runs of 16 rows straddle the images
+    (2, 20000, 26, 1.00, 0.03, 0.60, 500, True),       # 20000 candidates: a sort of two LDS blocks (32 768 slots)
+    (5, 8400, 27, 1.00, 0.03, 0.45, 1000, True),       # every anchor passes: one append per run of 16 rows
 ])
 def test_nms_random_vs_oracle_bit_exact(B, N, seed, hot, conf, iou, max_det, obj_one):
     from oracle import lp_post
