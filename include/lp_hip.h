@@ -157,11 +157,14 @@ int lp_engine_profile_ops(lp_engine* e, const void* x, int x_dtype, float* pred,
  * the current choice of an op: cfg = a workgroup tile of the implicit-GEMM kernel (0..5 = A..F) with
  * nbuf = LDS ring depth 1 or 2, or LP_VARIANT_STREAM64 / LP_VARIANT_STREAM128 (streaming 1x1 kernel with 64 / 128 output
  * channels per wave, nbuf 2), or LP_VARIANT_ROWS (row-writer form of a head_cls op, nbuf 1), or LP_VARIANT_PIPE_* (pipelined
- * 3x3 stride-1 kernel, nbuf 3).
+ * 3x3 stride-1 kernel, nbuf 3).  LP_VARIANT_PIPE_P belongs to the stem only (op 1, over the space-to-depth image the input op
+ * writes): with it the stem gathers its pixels from the caller's NCHW frame itself and the input op is skipped, whenever the
+ * frame passed to lp_engine_forward has the engine's 16-bit dtype (other dtypes: input op + the stem's other variant).
  * lp_engine_set_op_variant forces one (tests, experiments): LP_ERR_UNSUPPORTED if it does not fit the op. */
 enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18,
        /* pipelined 3x3 stride-1 kernel (persistent, 3-slot LDS ring, nbuf 3): 128 couts x 256 px, 64 x 512, 128 x 128, 32 x 512 */
-       LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35 };
+       LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35,
+       LP_VARIANT_PIPE_P = 36 /* 32 x 512, the stem reading the NCHW frame (see above) */ };
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);

@@ -539,6 +539,31 @@ def test_graph_mode_with_alternating_buffers():
     assert torch.equal(last, ref[11 % 2])
 
 
+@pytest.mark.parametrize('dtype,shape', [(torch.float16, (3, 3, 160, 224)), (torch.bfloat16, (2, 3, 96, 128)), (torch.float16, (1, 3, 640, 640))])
+def test_stem_reading_the_frame_itself_gives_the_same_bits(dtype, shape):
+    """LP_VARIANT_PIPE_P: the stem gathers its pixels from the caller's NCHW frame (no input op, no space-to-depth tensor in
+    between).  Same prediction bits as the input op + the stem's other kernels; a frame of another dtype takes that route."""
+    import ctypes
+    from yolov6.hip import runtime, abi
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=0.5, sigma=1.0).cuda().to(dtype)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(91)).cuda().to(dtype)
+    with torch.no_grad():
+        eng = runtime.engine_for(m)
+        eng.autotune = False
+        base = eng.forward(x).clone()                               # input op + default stem kernel
+        eng.set_variant(1, abi.LP_VARIANT_PIPE_P, 3)
+        cfg, nb = ctypes.c_int(), ctypes.c_int()
+        abi.check(eng.lib.lp_engine_op_variant(eng.h, 1, ctypes.byref(cfg), ctypes.byref(nb)), 'lp_engine_op_variant')
+        assert cfg.value == abi.LP_VARIANT_PIPE_P
+        assert torch.equal(eng.forward(x), base)
+        assert torch.equal(eng.forward(x.float()), base)            # fp32 frame: input op + the stem's other kernel
+        eng.set_variant(1, abi.LP_VARIANT_PIPE_C, 3)                # (also switches the planar form off again)
+        assert torch.equal(eng.forward(x), base)
+        with pytest.raises(RuntimeError):
+            eng.set_variant(2, abi.LP_VARIANT_PIPE_P, 3)            # only the stem has it
+
+
 def test_inflight_pipeline_matches_single_engine():
     """Several batches in flight (yolov6/core/pipeline.py): every batch gets the bits a single engine gives it, the
     other engines take over the first engine's tuning, and the results do not depend on the interleaving."""

@@ -51,7 +51,7 @@ int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H,
     return fail(LP_ERR_ARG, "input: x dtype");
 }
 
-// ---- input, space-to-depth form: NCHW [B,3,H,W] -> NHWC [B,H/2,W/2,16] with channel (py*2+px)*3 + c holding
+// ---- input, space-to-depth form: NCHW [B,3,H,W] -> NHWC [B,H/2,W/2,16] with channel c*4 + py*2 + px holding
 // x[c][2Y+py][2X+px] (12 real + 4 zero channels).  A 3x3 stride-2 conv of the image is then a stride-1 conv on this
 // tensor (taps (dy,py): (0,1)->ky 0, (1,0)->ky 1, (1,1)->ky 2; the third tap row/column has zero weights), which
 // runs on the stride-1 path of the MFMA kernel with a quarter of the halo.  One thread per output pixel: six
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void input_s2d_kernel(const TI* __restrict__ x
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const TI* p = x + (b * 3 + c) * HW + (long long)(2 * Y + py) * W + 2 * X;
-                row[(py * 2 + 0) * 3 + c] = (TO)(float)p[0];
-                row[(py * 2 + 1) * 3 + c] = (TO)(float)p[1];
+                row[c * 4 + py * 2 + 0] = (TO)(float)p[0];
+                row[c * 4 + py * 2 + 1] = (TO)(float)p[1];
             }
 #pragma unroll
         for (int k = 12; k < 16; ++k) row[k] = (TO)0.f;

@@ -181,6 +181,7 @@ ConvShape conv_pipe_shape(int pcfg) {
 }
 
 bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase) {
+    if (pcfg == PIPE_P) return false;     // the planar stem is chosen by the engine (it replaces the input op as well), never as a variant of a layer
     if (dtype == LP_F32 || pcfg < 0 || pcfg >= PIPE_COUNT || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
     const ConvShape s = conv_pipe_shape(pcfg);
     return s.CB == cb_pack && nct * s.CB <= 1024;   // 1024 = PIPE_MAXC (bias table in LDS)
@@ -201,7 +202,33 @@ static int device_cus() {   // CUs of the current device = persistent workgroups
     return g_ncu[dev];
 }
 
+// Output tile of the planar stem (lp_stem_planar.inc): TW a multiple of 4, TH * TW <= 512, the planar halo within a ring slot;
+// fewest tiles first, then the widest rows (longest contiguous runs of the frame).  `choice` = the k-th best.  false: none.
+bool stem_planar_tile(int Ho, int Wo, int choice, int* TH, int* TW) {
+    struct Cand { long long tiles; int th, tw; };
+    std::vector<Cand> cands;
+    for (int tw = 4; tw <= 512 && tw < Wo + 4; tw += 4) {
+        int th = 512 / tw;
+        if (th > Ho) th = Ho;
+        while (th >= 1 && ((th + 2) * 6 + 2) * (tw / 4 + 2) * 16 > 20 * 1024) --th;
+        if (th < 1) continue;
+        cands.push_back({(long long)ceil_div(Ho, th) * ceil_div(Wo, tw), th, tw});
+    }
+    std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.tiles != y.tiles ? x.tiles < y.tiles : x.tw > y.tw; });
+    if (choice < 0 || choice >= (int)cands.size()) return false;
+    *TH = cands[choice].th;
+    *TW = cands[choice].tw;
+    return true;
+}
+
 int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
+    if (pcfg == PIPE_P) {                 // the planar stem checks its own geometry
+        switch (dtype) {
+            case LP_F16: return conv_pipe_launch_f16(pcfg, a, device_cus(), st);
+            case LP_BF16: return conv_pipe_launch_bf16(pcfg, a, device_cus(), st);
+        }
+        return fail(LP_ERR_UNSUPPORTED, "planar stem: 16-bit frames only");
+    }
     const ConvShape s = conv_pipe_shape(pcfg);
     const int hh = a.TH + 2, hw = a.TW + 2;
     if (pcfg < 0 || pcfg >= PIPE_COUNT) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");

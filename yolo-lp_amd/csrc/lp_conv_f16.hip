@@ -3,6 +3,7 @@
 #include "lp_conv1x1_stream.inc"
 #include "lp_head_rows.inc"
 #include "lp_conv3x3_pipe.inc"
+#include "lp_stem_planar.inc"
 
 namespace lp {
 int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
@@ -12,5 +13,7 @@ int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
     return stream_launch_dtype<f16>(wc, a, cb_pack, lds, st);
 }
 int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_rows_launch_dtype<f16>(a, cb_pack, st); }
-int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) { return pipe_launch_dtype<f16>(pcfg, a, ncu, st); }
+int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) {
+    return pcfg == PIPE_P ? stem_planar_launch<f16>(a, ncu, st) : pipe_launch_dtype<f16>(pcfg, a, ncu, st);
+}
 }  // namespace lp

@@ -51,6 +51,8 @@ struct Op {
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
     size_t det_scratch = (size_t)-1;    // OP_HEAD_CLS whose detections-only form needs a prediction scratch: its arena offset (after bind)
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
+    int planar = 0;                     // stem over the space-to-depth image only: != 0: when the caller's frame has the engine's dtype, the
+                                        // PIPE_P kernel reads it directly and the input op is skipped (planar - 1 = its tile choice)
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
     size_t w_off = 0, b_off = 0, proj_off = 0;  // byte offsets in the packed blob
     long long w_phase_stride = 0;              // elements
@@ -105,7 +107,8 @@ struct lp_engine {
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
     unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe}
+    Launch stem_planar;               // ops[1] as the PIPE_P kernel (valid when ops[1].planar)
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar}
 };
 
 #define LP_MAX_LANES 3
@@ -365,7 +368,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
                         for (int kx = 0; kx < 3; ++kx) {
                             const int dy = ky == 0 ? 0 : 1, py = ky == 1 ? 0 : 1;   // image row 2*oy-1+ky = 2*(oy-1+dy) + py
                             const int dx = kx == 0 ? 0 : 1, px = kx == 1 ? 0 : 1;
-                            w2[(((size_t)co * 12 + (py * 2 + px) * 3 + ch) * 3 + dy) * 3 + dx] = c.weight[(((size_t)co * 3 + ch) * 3 + ky) * 3 + kx];
+                            w2[(((size_t)co * 12 + ch * 4 + py * 2 + px) * 3 + dy) * 3 + dx] = c.weight[(((size_t)co * 3 + ch) * 3 + ky) * 3 + kx];
                         }
             c.weight.swap(w2);
             c.src[0] = s2d_id;
@@ -576,7 +579,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -723,8 +726,28 @@ static int prepare_op(lp_engine* e, size_t idx) {
     L.rows = op.rows;
     L.pipe = op.pipe;
     L.cb_pack = cb_pack;
+    if (op.planar) {                    // the same layer as the PIPE_P kernel: its own tile geometry, src[0] patched per call
+        Launch& P = e->stem_planar;
+        P = L;
+        ConvArgs& pa = P.a;
+        if (pa.W % 4 != 0 || !stem_planar_tile(pa.Ho, pa.Wo, op.planar - 1, &pa.TH, &pa.TW))
+            return fail(LP_ERR_UNSUPPORTED, "planar stem: no tile for this frame size");
+        pa.tw_magic = (unsigned)(((1u << 22) + pa.TW - 1) / pa.TW);
+        pa.tiles_x = ceil_div(pa.Wo, pa.TW);
+        pa.tiles_y = ceil_div(pa.Ho, pa.TH);
+        pa.src[0].ptr = nullptr;
+        P.pipe = PIPE_P + 1;
+    }
     return LP_OK;
 }
+
+// The stem may read the caller's frame itself (PIPE_P) when the frame has the engine's 16-bit dtype.
+static bool stem_planar_possible(const lp_engine* e) {
+    return e->dtype != LP_F32 && e->ops.size() > 1 && e->ops[0].kind == OP_INPUT && e->ops[0].s2d && e->ops[1].kind == OP_CONV &&
+           e->ops[1].ksize == 3 && e->ops[1].stride == 1 && e->ops[1].mode == MODE_ACT && e->ops[1].nct == 1 && e->ops[1].nchunks == 1 &&
+           conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 32 && e->ops[1].res < 0;
+}
+static bool stem_planar_now(const lp_engine* e, int x_dtype) { return e->ops.size() > 1 && e->ops[1].planar && x_dtype == e->dtype; }
 
 // Detections-only forward: where the head ops write instead of the prediction tensor.
 struct DetCtx {
@@ -770,14 +793,21 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     const Op& op = e->ops[idx];
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
-    if (op.kind == OP_INPUT)
+    if (op.kind == OP_INPUT) {
+        if (op.s2d && stem_planar_now(e, x_dtype)) return LP_OK;         // the stem reads x itself
         return op.s2d ? input_s2d_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st)
                       : input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
+    }
     if (op.kind == OP_POOL) {
         const Tensor& t = e->tensors[op.src[0]];
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
+    if (idx == 1 && op.planar && stem_planar_now(e, x_dtype)) {
+        ConvArgs a = e->stem_planar.a;
+        a.src[0].ptr = x;
+        return conv_pipe_launch(dt, PIPE_P, a, st);
+    }
     if (L.mode == MODE_ACT && L.pipe) return conv_pipe_launch(dt, L.pipe - 1, L.a, st);
     if (L.mode == MODE_ACT && L.stream_wc) return conv_stream_launch(dt, L.stream_wc, L.a, L.cb_pack, st);
     if (L.mode == MODE_ACT) return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, L.a, st);
@@ -1091,11 +1121,38 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         op.stream_wc = best_pipe ? 0 : best_wc;
         op.stream_rd = best_rd;
         op.pipe = best_pipe;
+        op.planar = 0;
         rc = prepare_op(e, i);
         if (rc) return rc;
+        // the stem may read the caller's frame itself and make the input op unnecessary: worth it if it beats the two together
+        if (i == 1 && stem_planar_possible(e) && x_dtype == e->dtype && !getenv("LP_NO_PLANAR")) {
+            float t_in = -1.f;
+            for (int round = 0; round < 3 && trc == LP_OK; ++round) {
+                float ms = 0.f;
+                if (hipEventRecord(e0, st) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                for (int r = 0; r < reps; ++r) run_op(e, 0, x, x_dtype, pred, st);
+                if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                if (t_in < 0.f || ms < t_in) t_in = ms;
+            }
+            int best_planar = 0, last_th = -1, last_tw = -1;
+            float best_pl = -1.f;
+            for (int tile = 0; tile < 3 && trc == LP_OK && t_in >= 0.f; ++tile) {
+                op.planar = tile + 1;
+                if (prepare_op(e, i) != LP_OK) continue;
+                if (e->stem_planar.a.TH == last_th && e->stem_planar.a.TW == last_tw) break;
+                last_th = e->stem_planar.a.TH;
+                last_tw = e->stem_planar.a.TW;
+                const float ms = time_current();
+                if (ms >= 0.f && (best_pl < 0.f || ms < best_pl)) { best_pl = ms; best_planar = tile + 1; }
+            }
+            if (trc) return fail(trc, "autotune: event timing failed");
+            op.planar = (best_planar && best_pl < best_ms + t_in) ? best_planar : 0;
+            rc = prepare_op(e, i);
+            if (rc) return rc;
+        }
     }
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -1115,7 +1172,7 @@ extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
             for (size_t i = 0; i < dst->ops.size(); ++i) {
                 Op& op = dst->ops[i];
                 op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
-                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7];
                 int rc = prepare_op(dst, i);
                 if (rc) return rc;
             }
@@ -1137,6 +1194,15 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
+    if (cfg == LP_VARIANT_PIPE_D + PIPE_P) {      // the stem reading the caller's frame: on top of whatever variant runs for other frame dtypes
+        if (op_idx != 1 || !stem_planar_possible(e) || nbuf != 3)
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: only the stem over the space-to-depth image has the planar form");
+        op.planar = 1;
+        e->tuned.erase({e->B, e->H, e->W});
+        if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
+    op.planar = 0;
     if (cfg >= LP_VARIANT_PIPE_D && cfg < LP_VARIANT_PIPE_D + PIPE_COUNT) {
         const int pc = cfg - LP_VARIANT_PIPE_D;
         if (!conv_pipe_fits(e->dtype, pc, cb, ks, stv, op.mode, op.nct, op.nphase) || op.kind != OP_CONV || nbuf != 3)
@@ -1166,6 +1232,11 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;
+    if (e->ops[op].planar) {
+        if (cfg) *cfg = LP_VARIANT_PIPE_D + PIPE_P;
+        if (nbuf) *nbuf = 3;
+        return LP_OK;
+    }
     if (e->ops[op].pipe) {
         if (cfg) *cfg = LP_VARIANT_PIPE_D + e->ops[op].pipe - 1;
         if (nbuf) *nbuf = 3;
