@@ -51,11 +51,12 @@ void lp_engine_destroy(lp_engine* e);
  * Returns its id (>= 0) or a negative lp_status. */
 int lp_engine_tensor(lp_engine* e, int channels, int stride_log2);
 
-/* Execution lane (0..2) of the ops added from now on.  Lane 0 is the caller's stream; lanes 1 and 2 are side
+/* Execution lane (0..4) of the ops added from now on.  Lane 0 is the caller's stream; lanes 1..4 are side
  * streams of the engine.  Ops on different lanes may overlap; the engine derives every cross-lane dependency from
  * the tensors the ops read and write and forks / joins the side streams inside lp_engine_forward, so callers still
  * see one in-order forward on `stream`.  Used for the independent branches of BiFusion (common.py:523-527) and the
- * per-level towers of the head (effidehead.py:228-245). */
+ * per-level towers of the head (effidehead.py:228-245), which a builder may add right behind the neck layer that feeds them so
+ * that they run under the rest of the neck. */
 int lp_engine_set_lane(lp_engine* e, int lane);
 
 /* The network input: caller's NCHW image batch [B,3,H,W] -> tensor `dst` (declared with 3 channels,

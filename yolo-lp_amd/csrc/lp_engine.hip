@@ -71,7 +71,7 @@ struct Launch {
 using namespace lp;
 
 #ifndef LP_MAX_LANES
-#define LP_MAX_LANES 3
+#define LP_MAX_LANES 5
 #endif
 struct lp_engine {
     int dtype = LP_F16;
@@ -88,9 +88,9 @@ struct lp_engine {
     std::vector<hipEvent_t> events;
     int cur_lane = 0;                 // lane assigned to ops added from now on (lp_engine_set_lane)
     int n_lanes = 1;
-    hipStream_t lane_stream[LP_MAX_LANES] = {nullptr, nullptr, nullptr};   // [0] = the caller's stream
+    hipStream_t lane_stream[LP_MAX_LANES] = {};   // [0] = the caller's stream
     std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
-    hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
     struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
         hipGraphExec_t exec = nullptr;
@@ -111,7 +111,6 @@ struct lp_engine {
     std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar}
 };
 
-#define LP_MAX_LANES 3
 struct lp_engine;
 static int prepare_op(lp_engine* e, size_t idx);
 static unsigned long long* g_stamps = nullptr;
@@ -165,7 +164,7 @@ extern "C" int lp_engine_tensor(lp_engine* e, int channels, int stride_log2) {
 
 extern "C" int lp_engine_set_lane(lp_engine* e, int lane) {
     if (!e || e->finalized) return fail(LP_ERR_STATE, "lp_engine_set_lane: engine is null or frozen");
-    if (lane < 0 || lane >= LP_MAX_LANES) return fail(LP_ERR_ARG, "lp_engine_set_lane: lane must be 0..2");
+    if (lane < 0 || lane >= LP_MAX_LANES) return fail(LP_ERR_ARG, "lp_engine_set_lane: lane must be 0..4");
     e->cur_lane = lane;
     return LP_OK;
 }
