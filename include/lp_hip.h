@@ -222,6 +222,12 @@ enum { LP_EVAL_TRUE = 0, LP_EVAL_PRED = 1, LP_EVAL_PRED_BINS = 2, LP_EVAL_COR = 
 int lp_eval_counts(const float* det, const int32_t* det_count, int max_det, const float* tgt, const int32_t* tgt_count,
                    int max_t, int B, long long* counts, void* stream);
 
+/* Verification hook of the detections-only head (lp_engine_forward_det): it takes the largest sigmoid of a head to be the sigmoid of
+ * the head's largest logit, which holds iff the kernels' sigmoid (hardware exp2 and reciprocal) is monotone non-decreasing.  Checks
+ * every pair of neighbouring fp32 values (2^32 - 1 pairs, NaNs skipped) on the device and leaves the number of violations in
+ * *dev_violations (device memory, 8 bytes).  Expected: 0 (tests/test_hip_kernels.py). */
+int lp_check_sigmoid_monotone(unsigned long long* dev_violations, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

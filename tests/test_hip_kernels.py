@@ -515,3 +515,16 @@ def test_conv3x3_pipe(case, dtype):
             out = eng.tensor_view(dst)
             assert torch.equal(out, base), (cfg, rep, float((out.float() - base.float()).abs().max()))
     assert tried >= 1
+
+
+def test_sigmoid_of_the_kernels_is_monotone_over_all_of_fp32():
+    """The detections-only head computes max-of-sigmoids as sigmoid-of-max (lp_head_rows.inc): exact iff the kernels' sigmoid
+    (v_exp_f32 + v_rcp_f32) never decreases.  Checked for every pair of neighbouring fp32 values on the device."""
+    import ctypes
+    from yolov6.hip import abi
+    lib = abi.load()
+    bad = torch.full((1,), -1, dtype=torch.int64, device='cuda')
+    abi.check(lib.lp_check_sigmoid_monotone(ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              'lp_check_sigmoid_monotone')
+    torch.cuda.synchronize()
+    assert int(bad[0]) == 0
