@@ -25,4 +25,14 @@ python3 $root/tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE --ste
 # 4. counters of the pipelined kernel on the 256 -> 256 @ 40x40 layer
 bash $root/tools/micro/pmc_conv.sh $out/pmc_pd3 --batch 32 --k 3 --cin 256 --cout 256 --hw 40 --variant 32,3 > /dev/null 2>&1
 python3 $root/tools/micro/pmc_conv_summary.py $out/pmc_pd3 > $out/pmc_conv_256x256_40_Pd3.txt
+python3 $root/tools/micro/step_timeline.py $out/kt1 stem_planar Lb1E > $out/step_timeline_inflight1.txt 2>/dev/null || python3 $root/tools/micro/step_timeline.py $out/kt1 input_s2d Lb1E > $out/step_timeline_inflight1.txt
+# 5. the other single-GPU configurations of BASELINE.json (bench lines only)
+sec() { python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']
+print('$1', 'value', d['value'], 'value_inflight1', d['value_inflight1'], 'ms_per_step', d['ms_per_step'], '3x3 TFLOP/s', r['achieved'], 'forward_device_ms', r['forward_device_ms'], 'nms_device_ms', r['nms_device_ms'], 'step_ms_inflight1', d['step_ms_inflight1'])"; }
+: > $out/secondary_configs.txt
+timeout -k 10 300 python3 $root/bench.py --model yololpn --batch 128 --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | sec "yololpn 640 bs128 f16 (detections-only forward)" >> $out/secondary_configs.txt
+timeout -k 10 300 python3 $root/bench.py --model yololpn --batch 128 --steps 30 --warmup 3 --no-cpu-baseline --via-pred 2>/dev/null | sec "yololpn 640 bs128 f16 (--via-pred)" >> $out/secondary_configs.txt
+timeout -k 10 400 python3 $root/bench.py --model yolov6m --batch 8 --size 1280 --dtype bf16 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | sec "yolov6m 1280 bs8 bf16 (detections-only forward)" >> $out/secondary_configs.txt
+timeout -k 10 300 python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --via-pred 2>/dev/null | sec "yololps 640 bs32 f16 (--via-pred)" >> $out/secondary_configs.txt
 echo done; ls $out

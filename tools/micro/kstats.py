@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel summary of a rocprofv3 --kernel-trace CSV: calls, mean / total duration (us) per kernel, and -- the figure
 bench.py's roofline.avg_launch_ms has to agree with -- the mean duration of the 3x3 convolution launches of the TIMED steps:
-the last steps * launches_per_step dispatches of conv3x3_pipe_kernel / conv_mfma_kernel<.., KS = 3, ..> (everything before
+the last steps * launches_per_step dispatches of conv3x3_pipe_kernel / stem_planar_kernel / conv_mfma_kernel<.., KS = 3, ..> (everything before
 them is warm-up and the autotuner trying every kernel variant, which a --stats summary lumps in).
 
     python tools/micro/kstats.py <rocprof output dir> [--steps K --launches 47]
@@ -26,7 +26,7 @@ for f in glob.glob(a.dir + '/**/*kernel_trace.csv', recursive=True):
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         short = re.sub(r'^_ZN2lp\d+', '', n)[:70]
         acc[short].append(us)
-        if 'conv3x3_pipe_kernel' in n or re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', n):
+        if 'conv3x3_pipe_kernel' in n or 'stem_planar_kernel' in n or re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', n):
             conv3.append(us)
 tot = sum(sum(v) for v in acc.values())
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
