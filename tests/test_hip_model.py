@@ -564,6 +564,32 @@ def test_stem_reading_the_frame_itself_gives_the_same_bits(dtype, shape):
             eng.set_variant(2, abi.LP_VARIANT_PIPE_P, 3)            # only the stem has it
 
 
+@pytest.mark.parametrize('dtype,width,shape', [(torch.float16, 0.5, (2, 3, 160, 224)), (torch.bfloat16, 0.25, (3, 3, 96, 128)),
+                                               (torch.float16, 0.25, (1, 3, 64, 64)), (torch.float16, 0.5, (1, 3, 640, 640))])
+def test_fused_stem_and_first_stride2_layer_give_the_same_bits(dtype, width, shape):
+    """LP_VARIANT_FUSED_STEM2: input op + stem + ERBlock_2[0] as one kernel (the stem's output stays in LDS).  Same prediction bits
+    as the three ops run one after the other; a frame of another dtype takes that route; tile borders, image borders and both
+    template shapes (16 / 32 stem channels, 32 / 64 output channels) are covered by the sizes."""
+    import ctypes
+    from yolov6.hip import runtime, abi
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=width, sigma=1.0).cuda().to(dtype)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(92)).cuda().to(dtype)
+    with torch.no_grad():
+        eng = runtime.engine_for(m)
+        eng.autotune = False
+        base = eng.forward(x).clone()                               # input op + stem + conv, default kernels
+        eng.set_variant(2, abi.LP_VARIANT_FUSED_STEM2, 3)
+        cfg, nb = ctypes.c_int(), ctypes.c_int()
+        abi.check(eng.lib.lp_engine_op_variant(eng.h, 2, ctypes.byref(cfg), ctypes.byref(nb)), 'lp_engine_op_variant')
+        assert cfg.value == abi.LP_VARIANT_FUSED_STEM2
+        assert torch.equal(eng.forward(x), base)
+        assert torch.equal(eng.forward(x.float()), base)            # fp32 frame: the three ops
+        assert torch.equal(eng.forward(x), base)
+        with pytest.raises(RuntimeError):
+            eng.set_variant(3, abi.LP_VARIANT_FUSED_STEM2, 3)       # only the layer behind the stem has it
+
+
 def test_inflight_pipeline_matches_single_engine():
     """Several batches in flight (yolov6/core/pipeline.py): every batch gets the bits a single engine gives it, the
     other engines take over the first engine's tuning, and the results do not depend on the interleaving."""

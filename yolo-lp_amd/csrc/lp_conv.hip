@@ -221,8 +221,28 @@ bool stem_planar_tile(int Ho, int Wo, int choice, int* TH, int* TW) {
     return true;
 }
 
+// Output tile of the fused stem + ERBlock_2[0] kernel (lp_stem2_fused.inc): TW even, TH * TW <= 128, frame window and stem tile
+// within their LDS buffers; fewest stem positions computed in all (tiles x positions per tile).  `choice` = the k-th best.
+bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch) {
+    struct Cand { long long cost; int th, tw; };
+    std::vector<Cand> cands;
+    for (int tw = 2; tw <= 128 && tw < Wo + 2; tw += 2)
+        for (int th = 1; th <= 128 / tw && th <= Ho; ++th) {
+            const int hp4 = tw / 2 + 2, rin = 2 * th + 3, hps = 2 * tw + 2;
+            const int ntb = (th * tw + 31) / 32;                      // x cout blocks (1 or 2): 2 or 4 stores per wave only up to 8 / 16 tiles
+            if ((rin * 6 + 2) * hp4 * 16 > 21 * 1024 || (rin * 6 * hp4 + 63) / 64 > 24 || (2 * th + 1) * hps > 640 || ntb * 2 > 16) continue;
+            cands.push_back({(long long)ceil_div(Ho, th) * ceil_div(Wo, tw) * (2 * th + 1) * hps, th, tw});
+        }
+    std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.cost != y.cost ? x.cost < y.cost : x.tw > y.tw; });
+    if (choice < 0 || choice >= (int)cands.size()) return false;
+    *TH = cands[choice].th;
+    *TW = cands[choice].tw;
+    *hpitch = 2 * cands[choice].tw + 2;
+    return true;
+}
+
 int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
-    if (pcfg == PIPE_P) {                 // the planar stem checks its own geometry
+    if (pcfg == PIPE_P || pcfg == PIPE_FUSED2) {   // the planar stem kernels check their own geometry
         switch (dtype) {
             case LP_F16: return conv_pipe_launch_f16(pcfg, a, device_cus(), st);
             case LP_BF16: return conv_pipe_launch_bf16(pcfg, a, device_cus(), st);

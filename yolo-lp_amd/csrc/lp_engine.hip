@@ -51,6 +51,8 @@ struct Op {
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
     size_t det_scratch = (size_t)-1;    // OP_HEAD_CLS whose detections-only form needs a prediction scratch: its arena offset (after bind)
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
+    int fused = 0;                      // ERBlock_2[0] (op 2) only: != 0: when the caller's frame has the engine's dtype, input op, stem and this
+                                        // layer run as ONE kernel (lp_stem2_fused.inc; fused - 1 = its tile choice)
     int planar = 0;                     // stem over the space-to-depth image only: != 0: when the caller's frame has the engine's dtype, the
                                         // PIPE_P kernel reads it directly and the input op is skipped (planar - 1 = its tile choice)
     int chunk_begin[LP_MAX_SRC + 1] = {0, 0, 0, 0, 0};
@@ -108,7 +110,8 @@ struct lp_engine {
     unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
     Launch stem_planar;               // ops[1] as the PIPE_P kernel (valid when ops[1].planar)
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar}
+    Launch stem2_fused;               // ops[0..2] as the fused kernel (valid when ops[2].fused)
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar, fused}
 };
 
 struct lp_engine;
@@ -578,7 +581,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; e->ops[i].fused = it->second[i][8]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -737,6 +740,24 @@ static int prepare_op(lp_engine* e, size_t idx) {
         pa.src[0].ptr = nullptr;
         P.pipe = PIPE_P + 1;
     }
+    if (op.fused) {                     // input op + stem + this layer as one kernel: this layer's arguments + the stem's operands
+        const Op& stem = e->ops[1];
+        Launch& F = e->stem2_fused;
+        F = L;
+        ConvArgs& fa = F.a;
+        if (!stem2_fused_tile(fa.Ho, fa.Wo, op.fused - 1, &fa.TH, &fa.TW, &fa.hpitch))
+            return fail(LP_ERR_UNSUPPORTED, "fused stem: no tile for this frame size");
+        fa.tw_magic = (unsigned)(((1u << 22) + fa.TW - 1) / fa.TW);
+        fa.hp_magic = (unsigned)(((1u << 22) + fa.hpitch - 1) / fa.hpitch);
+        fa.tiles_x = ceil_div(fa.Wo, fa.TW);
+        fa.tiles_y = ceil_div(fa.Ho, fa.TH);
+        fa.src[0].ptr = nullptr;
+        fa.fz_w1 = e->dev_w + stem.w_off;
+        fa.fz_b1 = (const float*)(e->dev_w + stem.b_off);
+        fa.fz_act1 = stem.act;
+        fa.fz_c1 = e->tensors[stem.dst].cs;
+        F.pipe = PIPE_FUSED2 + 1;
+    }
     return LP_OK;
 }
 
@@ -747,6 +768,24 @@ static bool stem_planar_possible(const lp_engine* e) {
            conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 32 && e->ops[1].res < 0;
 }
 static bool stem_planar_now(const lp_engine* e, int x_dtype) { return e->ops.size() > 1 && e->ops[1].planar && x_dtype == e->dtype; }
+// ... and run together with the layer behind it (lp_stem2_fused.inc) when that is a 3x3 stride-2 layer of at most 64 output channels
+// and the stem's output (at most 32 channels) has no other reader.
+static bool stem2_fused_possible(const lp_engine* e) {
+    if (!stem_planar_possible(e) || e->ops.size() < 3) return false;
+    const Op& s = e->ops[1];
+    const Op& c = e->ops[2];
+    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.src[0] != s.dst || c.res >= 0 || c.mode != MODE_ACT ||
+        c.nct != 1 || c.nphase != 1 || c.nchunks < 1 || c.nchunks > 2) return false;
+    const int cb = conv_shape(e->dtype, c.cfg, 3, 2).CB, cs2 = e->tensors[c.dst].cs;
+    if ((cb != 32 && cb != 64) || cb != 32 * ((cs2 + 31) / 32) || e->tensors[s.dst].cs > 16 * c.nchunks) return false;
+    for (size_t i = 3; i < e->ops.size(); ++i) {
+        const Op& o = e->ops[i];
+        for (int k = 0; k < o.nsrc; ++k) if (o.src[k] == s.dst) return false;
+        if (o.res == s.dst) return false;
+    }
+    return true;
+}
+static bool stem2_fused_now(const lp_engine* e, int x_dtype) { return e->ops.size() > 2 && e->ops[2].fused && x_dtype == e->dtype; }
 
 // Detections-only forward: where the head ops write instead of the prediction tensor.
 struct DetCtx {
@@ -793,7 +832,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
     if (op.kind == OP_INPUT) {
-        if (op.s2d && stem_planar_now(e, x_dtype)) return LP_OK;         // the stem reads x itself
+        if (op.s2d && (stem_planar_now(e, x_dtype) || stem2_fused_now(e, x_dtype))) return LP_OK;   // the stem reads x itself
         return op.s2d ? input_s2d_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st)
                       : input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
     }
@@ -802,6 +841,12 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
+    if (idx == 1 && stem2_fused_now(e, x_dtype)) return LP_OK;            // runs inside the fused kernel of op 2
+    if (idx == 2 && stem2_fused_now(e, x_dtype)) {
+        ConvArgs a = e->stem2_fused.a;
+        a.src[0].ptr = x;
+        return conv_pipe_launch(dt, PIPE_FUSED2, a, st);
+    }
     if (idx == 1 && op.planar && stem_planar_now(e, x_dtype)) {
         ConvArgs a = e->stem_planar.a;
         a.src[0].ptr = x;
@@ -1121,6 +1166,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         op.stream_rd = best_rd;
         op.pipe = best_pipe;
         op.planar = 0;
+        op.fused = 0;
         rc = prepare_op(e, i);
         if (rc) return rc;
         // the stem may read the caller's frame itself and make the input op unnecessary: worth it if it beats the two together
@@ -1149,9 +1195,42 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             rc = prepare_op(e, i);
             if (rc) return rc;
         }
+        // ... or run as one kernel with the layer behind it: against the three ops as tuned so far
+        if (i == 2 && stem2_fused_possible(e) && x_dtype == e->dtype && !getenv("LP_NO_PLANAR") && !getenv("LP_NO_FUSED_STEM")) {
+            auto time_ops = [&](size_t first, size_t last) -> float {     // best of three rounds of `reps` x (ops first..last)
+                float ms_min = -1.f;
+                for (int round = 0; round < 3 && trc == LP_OK; ++round) {
+                    float ms = 0.f;
+                    if (hipEventRecord(e0, st) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    for (int r = 0; r < reps; ++r)
+                        for (size_t k = first; k <= last; ++k) run_op(e, k, x, x_dtype, pred, st);
+                    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+                }
+                return ms_min;
+            };
+            op.fused = 0;
+            const float t_sep = time_ops(0, 2);
+            int best_f = 0, last_th = -1, last_tw = -1;
+            float best_fms = -1.f;
+            for (int tile = 0; tile < 3 && trc == LP_OK && t_sep >= 0.f; ++tile) {
+                op.fused = tile + 1;
+                if (prepare_op(e, i) != LP_OK) continue;
+                if (e->stem2_fused.a.TH == last_th && e->stem2_fused.a.TW == last_tw) break;
+                last_th = e->stem2_fused.a.TH;
+                last_tw = e->stem2_fused.a.TW;
+                if (run_op(e, 2, x, x_dtype, pred, st) != LP_OK) continue;
+                const float ms = time_ops(2, 2);
+                if (ms >= 0.f && (best_fms < 0.f || ms < best_fms)) { best_fms = ms; best_f = tile + 1; }
+            }
+            if (trc) return fail(trc, "autotune: event timing failed");
+            op.fused = (best_f && best_fms < t_sep) ? best_f : 0;
+            rc = prepare_op(e, i);
+            if (rc) return rc;
+        }
     }
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar, op.fused});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -1171,7 +1250,7 @@ extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
             for (size_t i = 0; i < dst->ops.size(); ++i) {
                 Op& op = dst->ops[i];
                 op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
-                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7]; op.fused = it->second[i][8];
                 int rc = prepare_op(dst, i);
                 if (rc) return rc;
             }
@@ -1193,6 +1272,15 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
+    if (cfg == LP_VARIANT_FUSED_STEM2) {          // stem + this layer as one kernel: on top of whatever variants run for other frame dtypes
+        if (op_idx != 2 || !stem2_fused_possible(e) || nbuf != 3)
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: only the layer behind the stem (3x3 stride 2, <= 64 channels) has the fused form");
+        op.fused = 1;
+        e->tuned.erase({e->B, e->H, e->W});
+        if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
+    op.fused = 0;
     if (cfg == LP_VARIANT_PIPE_D + PIPE_P) {      // the stem reading the caller's frame: on top of whatever variant runs for other frame dtypes
         if (op_idx != 1 || !stem_planar_possible(e) || nbuf != 3)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: only the stem over the space-to-depth image has the planar form");
@@ -1231,6 +1319,11 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;
+    if (e->ops[op].fused) {
+        if (cfg) *cfg = LP_VARIANT_FUSED_STEM2;
+        if (nbuf) *nbuf = 3;
+        return LP_OK;
+    }
     if (e->ops[op].planar) {
         if (cfg) *cfg = LP_VARIANT_PIPE_D + PIPE_P;
         if (nbuf) *nbuf = 3;

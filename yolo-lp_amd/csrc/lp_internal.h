@@ -44,7 +44,8 @@ enum ConvMode { MODE_ACT = 0, MODE_PRED = 1, MODE_DECODE = 2 };
 enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C = 2 /*32 x 256*/, CFG_D = 3 /*128 x 256, 8 waves*/, CFG_E = 4 /*64 x 128, 4 waves of 32x64*/, CFG_F = 5 /*128 x 128, 8 waves of 32x64*/, CFG_COUNT = 6 };
 
 // Pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc): workgroup configurations
-enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5 };
+enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
+                 PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/ };
 
 struct ConvSrc {
     const void* ptr;
@@ -86,6 +87,10 @@ struct ConvArgs {
     int* det_cnt;
     int det_np, det_n, det_anchor0;   // keys per image (power of two), anchors per image, first anchor of this level
     float det_conf;
+    // stem2_fused_kernel (lp_stem2_fused.inc): the stem's packed weights, bias, activation and stored channels (src[0] = the frame)
+    const void* fz_w1;
+    const float* fz_b1;
+    int fz_act1, fz_c1;
     // MODE_DECODE
     int reg_bins;
     const float* proj;
@@ -103,6 +108,7 @@ void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, i
 int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 bool stem_planar_tile(int Ho, int Wo, int choice, int* TH, int* TW);   // lp_stem_planar.inc's output tile (choice = k-th best); false: none
+bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch);   // lp_stem2_fused.inc's output tile and stem-tile pitch
 
 // Streaming 1x1 kernel (lp_conv1x1_stream.inc): wc = cout tiles per wave (2 or 4), cb_pack = cout-tile rows of the op's
 // weight packing.  conv_stream_lds() < 0: the layer does not fit.
