@@ -298,7 +298,7 @@ def main():
         roofline = {
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_source': traffic_note,
-            'kernel': '3x3 convolutions (conv3x3_pipe_kernel / stem_planar_kernel / conv_mfma_kernel<KS=3>, implicit GEMM, all %d launches of a step)' % len(conv3),
+            'kernel': '3x3 convolution layers (conv3x3_pipe_kernel / stem2_fused_kernel = stem + the layer behind it / conv_mfma_kernel<KS=3>, implicit GEMM, all %d of a step)' % len(conv3),
             'timing': 'hipEvent pairs on the launch stream around %d back-to-back launches of each op' % max(1, args.profile_inner),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),

@@ -12,20 +12,20 @@ timeout -k 10 280 python3 $root/bench.py --steps 50 --warmup 5 --detail $out/per
 # 2. the same command under rocprofv3 --kernel-trace --stats
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_rocprof.json 2> $out/bench_rocprof.err || exit 2
 cp $(ls $out/kt/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-python3 $root/tools/micro/kstats.py $out/kt --steps 50 --launches 47 > $out/kernel_summary_inflight6.txt
+python3 $root/tools/micro/kstats.py $out/kt --steps 50 --launches 46 > $out/kernel_summary_inflight6.txt
 # 2b. one batch in flight (kernels of different batches do not overlap): the durations bench.py's per-op timing has to agree with
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -o kt -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --inflight 1 > $out/bench_rocprof_inflight1.json 2> $out/bench_rocprof_inflight1.err || exit 2
 cp $(ls $out/kt1/*kernel_stats.csv | head -1) $out/kernel_stats_inflight1.csv
-python3 $root/tools/micro/kstats.py $out/kt1 --steps 100 --launches 47 > $out/kernel_summary_inflight1.txt
+python3 $root/tools/micro/kstats.py $out/kt1 --steps 100 --launches 46 > $out/kernel_summary_inflight1.txt
 # 3. HBM traffic of the 3x3 launches: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), one batch in flight, the reference-shaped path
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> $out/pmc_$c.err || exit 3
 done
-python3 $root/tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE --steps 3 --launches 47 > $out/pmc_traffic.json || exit 4
+python3 $root/tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE --steps 3 --launches 46 > $out/pmc_traffic.json || exit 4
 # 4. counters of the pipelined kernel on the 256 -> 256 @ 40x40 layer
 bash $root/tools/micro/pmc_conv.sh $out/pmc_pd3 --batch 32 --k 3 --cin 256 --cout 256 --hw 40 --variant 32,3 > /dev/null 2>&1
 python3 $root/tools/micro/pmc_conv_summary.py $out/pmc_pd3 > $out/pmc_conv_256x256_40_Pd3.txt
-python3 $root/tools/micro/step_timeline.py $out/kt1 stem_planar Lb1E > $out/step_timeline_inflight1.txt 2>/dev/null || python3 $root/tools/micro/step_timeline.py $out/kt1 input_s2d Lb1E > $out/step_timeline_inflight1.txt
+python3 $root/tools/micro/step_timeline.py $out/kt1 stem2_fused Lb1E > $out/step_timeline_inflight1.txt 2>/dev/null || python3 $root/tools/micro/step_timeline.py $out/kt1 stem_planar Lb1E > $out/step_timeline_inflight1.txt 2>/dev/null || python3 $root/tools/micro/step_timeline.py $out/kt1 input_s2d Lb1E > $out/step_timeline_inflight1.txt
 # 5. the other single-GPU configurations of BASELINE.json (bench lines only)
 sec() { python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']

@@ -27,7 +27,7 @@ def last_values(d, counter, n):
     vals = []
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k or 'stem_planar_kernel' in k):
+        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k or 'stem_planar_kernel' in k or 'stem2_fused_kernel' in k):
             vals.append(float(r['Counter_Value']))
     return vals[-n:]
 
@@ -36,14 +36,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument('fetch_dir')
 ap.add_argument('write_dir')
 ap.add_argument('--steps', type=int, default=3)
-ap.add_argument('--launches', type=int, default=47)
+ap.add_argument('--launches', type=int, default=47, help='3x3 kernel dispatches per step')
+ap.add_argument('--layers', type=int, default=47, help='3x3 layers per step (the fused stem kernel runs two of them): the per-launch figures are per LAYER, like bench.py roofline')
 a = ap.parse_args()
 n = a.steps * a.launches
 fetch = last_values(a.fetch_dir, 'FETCH_SIZE', n)
 write = last_values(a.write_dir, 'WRITE_SIZE', n)
-fetch_b = sum(fetch) / len(fetch) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
-write_b = sum(write) / len(write) * 1024
-print(json.dumps({'kernel': '3x3 conv launches (conv3x3_pipe_kernel + stem_planar_kernel + conv_mfma_kernel<KS=3>)', 'kernel_source_hash': source_hash(),
+fetch_b = sum(fetch) / (a.steps * a.layers) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
+write_b = sum(write) / (a.steps * a.layers) * 1024
+print(json.dumps({'kernel': '3x3 conv layers (conv3x3_pipe_kernel + stem2_fused_kernel / stem_planar_kernel + conv_mfma_kernel<KS=3>), bytes per LAYER', 'kernel_source_hash': source_hash(),
                   'dispatches_averaged': len(fetch),
                   'fetch_bytes_per_launch': round(fetch_b), 'write_bytes_per_launch': round(write_b),
                   'hbm_bytes_per_launch': round(fetch_b + write_b),
