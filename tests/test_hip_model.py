@@ -585,6 +585,9 @@ def test_fused_stem_and_first_stride2_layer_give_the_same_bits(dtype, width, sha
         assert cfg.value == abi.LP_VARIANT_FUSED_STEM2
         assert torch.equal(eng.forward(x), base)
         assert torch.equal(eng.forward(x.float()), base)            # fp32 frame: the three ops
+        xu = torch.empty(x.numel() + 8, dtype=dtype, device='cuda')[1:1 + x.numel()].view_as(x)
+        xu.copy_(x)                                                  # a frame that is not 16-byte aligned: the three ops as well
+        assert xu.data_ptr() % 16 != 0 and torch.equal(eng.forward(xu), base)
         assert torch.equal(eng.forward(x), base)
         with pytest.raises(RuntimeError):
             eng.set_variant(3, abi.LP_VARIANT_FUSED_STEM2, 3)       # only the layer behind the stem has it

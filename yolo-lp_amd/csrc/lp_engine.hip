@@ -767,7 +767,9 @@ static bool stem_planar_possible(const lp_engine* e) {
            e->ops[1].ksize == 3 && e->ops[1].stride == 1 && e->ops[1].mode == MODE_ACT && e->ops[1].nct == 1 && e->ops[1].nchunks == 1 &&
            conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 32 && e->ops[1].res < 0;
 }
-static bool stem_planar_now(const lp_engine* e, int x_dtype) { return e->ops.size() > 1 && e->ops[1].planar && x_dtype == e->dtype; }
+// (the frame must have the engine's dtype and be 16-byte aligned -- the kernels copy it in 16-byte pieces; anything else takes the input op)
+static bool frame_direct(const lp_engine* e, const void* x, int x_dtype) { return x_dtype == e->dtype && ((uintptr_t)x & 15) == 0; }
+static bool stem_planar_now(const lp_engine* e, const void* x, int x_dtype) { return e->ops.size() > 1 && e->ops[1].planar && frame_direct(e, x, x_dtype); }
 // ... and run together with the layer behind it (lp_stem2_fused.inc) when that is a 3x3 stride-2 layer of at most 64 output channels
 // and the stem's output (at most 32 channels) has no other reader.
 static bool stem2_fused_possible(const lp_engine* e) {
@@ -785,7 +787,7 @@ static bool stem2_fused_possible(const lp_engine* e) {
     }
     return true;
 }
-static bool stem2_fused_now(const lp_engine* e, int x_dtype) { return e->ops.size() > 2 && e->ops[2].fused && x_dtype == e->dtype; }
+static bool stem2_fused_now(const lp_engine* e, const void* x, int x_dtype) { return e->ops.size() > 2 && e->ops[2].fused && frame_direct(e, x, x_dtype); }
 
 // Detections-only forward: where the head ops write instead of the prediction tensor.
 struct DetCtx {
@@ -832,7 +834,7 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     const int dt = e->dtype;
     auto tptr = [&](int id) { return (void*)(e->arena + e->tensors[id].offset); };
     if (op.kind == OP_INPUT) {
-        if (op.s2d && (stem_planar_now(e, x_dtype) || stem2_fused_now(e, x_dtype))) return LP_OK;   // the stem reads x itself
+        if (op.s2d && (stem_planar_now(e, x, x_dtype) || stem2_fused_now(e, x, x_dtype))) return LP_OK;   // the stem reads x itself
         return op.s2d ? input_s2d_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st)
                       : input_launch(x, x_dtype, tptr(op.dst), dt, e->B, e->H, e->W, st);
     }
@@ -841,13 +843,13 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
-    if (idx == 1 && stem2_fused_now(e, x_dtype)) return LP_OK;            // runs inside the fused kernel of op 2
-    if (idx == 2 && stem2_fused_now(e, x_dtype)) {
+    if (idx == 1 && stem2_fused_now(e, x, x_dtype)) return LP_OK;            // runs inside the fused kernel of op 2
+    if (idx == 2 && stem2_fused_now(e, x, x_dtype)) {
         ConvArgs a = e->stem2_fused.a;
         a.src[0].ptr = x;
         return conv_pipe_launch(dt, PIPE_FUSED2, a, st);
     }
-    if (idx == 1 && op.planar && stem_planar_now(e, x_dtype)) {
+    if (idx == 1 && op.planar && stem_planar_now(e, x, x_dtype)) {
         ConvArgs a = e->stem_planar.a;
         a.src[0].ptr = x;
         return conv_pipe_launch(dt, PIPE_P, a, st);
@@ -1170,7 +1172,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         rc = prepare_op(e, i);
         if (rc) return rc;
         // the stem may read the caller's frame itself and make the input op unnecessary: worth it if it beats the two together
-        if (i == 1 && stem_planar_possible(e) && x_dtype == e->dtype && !getenv("LP_NO_PLANAR")) {
+        if (i == 1 && stem_planar_possible(e) && frame_direct(e, x, x_dtype) && !getenv("LP_NO_PLANAR")) {
             float t_in = -1.f;
             for (int round = 0; round < 3 && trc == LP_OK; ++round) {
                 float ms = 0.f;
@@ -1196,7 +1198,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             if (rc) return rc;
         }
         // ... or run as one kernel with the layer behind it: against the three ops as tuned so far
-        if (i == 2 && stem2_fused_possible(e) && x_dtype == e->dtype && !getenv("LP_NO_PLANAR") && !getenv("LP_NO_FUSED_STEM")) {
+        if (i == 2 && stem2_fused_possible(e) && frame_direct(e, x, x_dtype) && !getenv("LP_NO_PLANAR") && !getenv("LP_NO_FUSED_STEM")) {
             auto time_ops = [&](size_t first, size_t last) -> float {     // best of three rounds of `reps` x (ops first..last)
                 float ms_min = -1.f;
                 for (int round = 0; round < 3 && trc == LP_OK; ++round) {
