@@ -240,7 +240,7 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
 // to bit operations: every IoU test it needs has been made a chunk earlier, in parallel.  Per chunk c, between two barriers:
 //   waves 1..  take chunk c + 1 (one candidate per lane; the box it is tested against is wave-uniform):
 //              against the kept list as it stood at the barrier (a share of the list per wave, one broadcast ds_read_b128
-//              per test)                                          -> dead[(c + 1) & 1]   bit j: candidate j is suppressed
+//              per test)                                          -> dead[(c + 1) % 3]   bit j: candidate j is suppressed
 //              against the 64 candidates of chunk c (v_readlane)  -> xt[(c + 1) & 1][j]  bit k: candidate k of chunk c overlaps j
 //              against the earlier candidates of its own chunk    -> mt[(c + 1) & 1][j]  bit k: candidate k < j overlaps j
 //   wave 0     takes chunk c: alive = not dead, and no survivor of chunk c - 1 in xt; then in candidate order: the first
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
     extern __shared__ __attribute__((aligned(16))) box4 kbox[];      // [kcap] the first kept boxes, then [kcap] their anchors
     __shared__ __attribute__((aligned(16))) box4 cbox[2][NMS_T];     // two staged batches of candidates
     __shared__ int canchor[2][NMS_T];
-    __shared__ unsigned long long dead[2], xt[2][64], mt[2][64];
+    __shared__ unsigned long long dead[3], xt[2][64], mt[2][64];     // dead: chunk c's mask lives in dead[c % 3] (read by everyone during iteration c)
     __shared__ int s_nk[2];
     int* const kanchor = (int*)(kbox + kcap);
     constexpr int NSW = NMS_T / 64 - 1;                // striking waves
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
     int fa = fetch_anchor(0);
     box4 fb = fetch_box(fa);
     cbox[0][tid] = fb; canchor[0][tid] = fa;
-    if (tid < 2) dead[tid] = 0;
+    if (tid < 3) dead[tid] = 0;
     if (tid < 128) { xt[tid >> 6][tid & 63] = 0; mt[tid >> 6][tid & 63] = 0; }
     __syncthreads();
 
@@ -296,9 +296,11 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
         return o;
     };
     // bit k of the result: candidate k of `from` (k in this wave's share; below `lane` if `earlier_only`) overlaps this lane's box
-    auto pair_mask = [&](const box4& from, const box4& mine, bool earlier_only) {
+    // Candidates of `from` that the kept list has already suppressed (`gone`) can never survive, so what they overlap does not matter.
+    auto pair_mask = [&](const box4& from, const box4& mine, bool earlier_only, unsigned long long gone) {
         unsigned long long m = 0;
         for (int k = wave - 1; k < 64; k += NSW) {
+            if ((gone >> k) & 1ull) continue;                     // wave-uniform
             const box4 q = bcast(from, k);
             if ((!earlier_only || lane > k) && iou_gt(q.x, q.y, q.z, q.w, area_of(q), mine.x, mine.y, mine.z, mine.w, thr_f)) m |= 1ull << k;
         }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
 
     box4 bx = chunk_box(0);                            // (waves 1..: the chunk before theirs)
     if (wave != 0) {                                   // chunk 0 against itself
-        const unsigned long long m = pair_mask(bx, bx, true);
+        const unsigned long long m = pair_mask(bx, bx, true, 0ull);
         if (m) atomicOr(&mt[0][lane], m);
     }
     __syncthreads();
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
             bx = chunk_box(c);
             const int anchor = canchor[(c / NMS_BATCH) & 1][(c % NMS_BATCH) * 64 + lane];
             const int i = c * 64 + lane;
-            const bool alive = i < nc && !((dead[p] >> lane) & 1ull) && (xt[p][lane] & kept_prev) == 0;
+            const bool alive = i < nc && !((dead[c % 3] >> lane) & 1ull) && (xt[p][lane] & kept_prev) == 0;
             const unsigned long long mrow = mt[p][lane];
-            if (lane == 0) dead[p] = 0;                // next written (for chunk c + 2) behind the barrier
+            if (lane == 0) dead[(c + 2) % 3] = 0;      // chunk c - 1's mask: nobody reads it any more; next written (for chunk c + 2) behind the barrier
             xt[p][lane] = 0;
             mt[p][lane] = 0;
             unsigned long long todo = __ballot(alive);
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
             auto test = [&](const box4& q) { return iou_gt(q.x, q.y, q.z, q.w, area_of(q), bx.x, bx.y, bx.z, bx.w, thr_f); };
             auto share = [&]() {                       // false: all 64 are dead
                 const unsigned long long m = __ballot(dd);
-                if (lane == 0 && m) atomicOr(&dead[p ^ 1], m);
-                dd = (dead[p ^ 1] >> lane) & 1ull;
+                if (lane == 0 && m) atomicOr(&dead[(c + 1) % 3], m);
+                dd = (dead[(c + 1) % 3] >> lane) & 1ull;
                 return __ballot(!dd) != 0;
             };
             bool more = true;
@@ -374,12 +376,19 @@ __global__ __launch_bounds__(NMS_T) void greedy_kernel(const unsigned long long*
                 for (; k < T; k += NSW)
                     if (!dd) dd = test(sb[k]);
                 const unsigned long long m = __ballot(dd);
-                if (lane == 0 && m) atomicOr(&dead[p ^ 1], m);
+                if (lane == 0 && m) atomicOr(&dead[(c + 1) % 3], m);
             }
-            const unsigned long long xm = pair_mask(pbx, bx, false);
-            if (xm) atomicOr(&xt[p ^ 1][lane], xm);
-            const unsigned long long mm = pair_mask(bx, bx, true);
-            if (mm) atomicOr(&mt[p ^ 1][lane], mm);
+            // pair tests only against candidates that can still survive: chunk c's mask is complete, chunk c + 1's as far as
+            // the waves have published it (any bit set is final); this lane's own tests are skipped once it is gone itself
+            const unsigned long long gone_c = dead[c % 3], gone_n = dead[(c + 1) % 3];
+            const bool me_gone = (gone_n >> lane) & 1ull;
+            unsigned long long xm = 0, mm = 0;
+            if (!__builtin_expect(__ballot(!me_gone) == 0ull, 0)) {
+                xm = pair_mask(pbx, bx, false, gone_c);
+                mm = pair_mask(bx, bx, true, gone_n);
+            }
+            if (xm && !me_gone) atomicOr(&xt[p ^ 1][lane], xm);
+            if (mm && !me_gone) atomicOr(&mt[p ^ 1][lane], mm);
         }
         if (c % NMS_BATCH == NMS_BATCH - 2) {           // -> the buffer whose last chunk was read a chunk ago
             const int g = c / NMS_BATCH + 1;
