@@ -230,6 +230,12 @@ int lp_eval_counts(const float* det, const int32_t* det_count, int max_det, cons
  * *dev_violations (device memory, 8 bytes).  Expected: 0 (tests/test_hip_kernels.py). */
 int lp_check_sigmoid_monotone(unsigned long long* dev_violations, void* stream);
 
+/* Host-side planning of the frame-reading stem kernels (no device needed; used by the CPU tests): the `choice`-th best output tile
+ * TH x TW for an Ho x Wo output map of stem_planar_kernel (fused == 0: TW % 4 == 0, TH * TW <= 512, planar halo within its 20 KiB LDS
+ * slot) or of stem2_fused_kernel (fused != 0: TW even, TH * TW <= 128, frame window <= 21 KiB, stem tile pitch *hpitch >= 2 TW + 1 with
+ * (2 TH + 1) * pitch <= 640 positions).  LP_ERR_UNSUPPORTED: no such tile. */
+int lp_plan_stem_tile(int fused, int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,3 +142,28 @@ def test_engine_cache_stays_out_of_the_module_state():
     assert m not in runtime._engines
     with pytest.raises(TypeError):
         pickle.dumps(runtime.Engine.__new__(runtime.Engine))
+
+
+def test_stem_tile_planning_respects_the_kernels_limits():
+    """lp_plan_stem_tile: the tiles the engine hands to stem_planar_kernel / stem2_fused_kernel cover the map and stay inside
+    the kernels' LDS buffers and alignment rules, for every output size a multiple-of-32 frame can give."""
+    from yolov6.hip import abi
+    lib = abi.load()
+    th, tw, hp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for ho, wo in [(320, 320), (160, 160), (16, 16), (8, 8), (48, 64), (640, 640), (24, 200), (320, 8), (80, 112)]:
+        for fused in (0, 1):
+            seen = set()
+            for choice in range(3):
+                rc = lib.lp_plan_stem_tile(fused, ho, wo, choice, ctypes.byref(th), ctypes.byref(tw), ctypes.byref(hp))
+                if rc != 0:
+                    assert choice > 0, (fused, ho, wo)            # there is always a first choice
+                    break
+                t = (th.value, tw.value)
+                assert t not in seen and 1 <= t[0] <= ho
+                seen.add(t)
+                if fused:
+                    assert t[1] % 2 == 0 and t[0] * t[1] <= 128 and hp.value >= 2 * t[1] + 1 and (2 * t[0] + 1) * hp.value <= 640
+                    assert ((2 * t[0] + 3) * 6 + 2) * (t[1] // 2 + 2) * 16 <= 21 * 1024
+                else:
+                    assert t[1] % 4 == 0 and t[0] * t[1] <= 512 and ((t[0] + 2) * 6 + 2) * (t[1] // 4 + 2) * 16 <= 20 * 1024
+    assert lib.lp_plan_stem_tile(0, 0, 8, 0, ctypes.byref(th), ctypes.byref(tw), None) < 0

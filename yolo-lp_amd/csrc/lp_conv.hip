@@ -286,3 +286,13 @@ int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) 
 }
 
 }  // namespace lp
+
+// Host-side planning of the two frame-reading stem kernels, exported for the CPU tests of the host logic (no device needed).
+extern "C" int lp_plan_stem_tile(int fused, int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch) {
+    if (!TH || !TW || Ho < 1 || Wo < 1) return lp::fail(LP_ERR_ARG, "lp_plan_stem_tile: bad arguments");
+    int hp = 0;
+    const bool ok = fused ? lp::stem2_fused_tile(Ho, Wo, choice, TH, TW, &hp) : lp::stem_planar_tile(Ho, Wo, choice, TH, TW);
+    if (hpitch) *hpitch = hp;
+    return ok ? LP_OK : LP_ERR_UNSUPPORTED;
+}
+

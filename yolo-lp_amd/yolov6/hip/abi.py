@@ -68,6 +68,7 @@ SYMBOLS = {
     'lp_rescale_round': (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     'lp_eval_counts': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'lp_check_sigmoid_monotone': (c_int, [c_void_p, c_void_p]),
+    'lp_plan_stem_tile': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_size_t, c_void_p]),
 }
