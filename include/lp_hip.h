@@ -167,7 +167,9 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
        LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35,
        LP_VARIANT_PIPE_P = 36 /* 32 x 512, the stem reading the NCHW frame (see above) */,
        LP_VARIANT_FUSED_STEM2 = 37 /* op 2 only (3x3 stride 2 behind the stem, <= 64 channels): input op + stem + this layer as ONE kernel
-                                      whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */ };
+                                      whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */,
+       LP_VARIANT_FUSED_PW_S2 = 38 /* a 3x3 stride-2 layer (<= 64 channels) whose input comes from a 1x1 layer (64 -> <= 64 channels) that nobody
+                                      else reads (BiFusion's downsample(cv2(x)), common.py:504-527): the two as ONE kernel; the 1x1 op is skipped */ };
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);

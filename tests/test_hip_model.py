@@ -593,6 +593,33 @@ def test_fused_stem_and_first_stride2_layer_give_the_same_bits(dtype, width, sha
             eng.set_variant(3, abi.LP_VARIANT_FUSED_STEM2, 3)       # only the layer behind the stem has it
 
 
+@pytest.mark.parametrize('dtype,shape', [(torch.float16, (2, 3, 160, 224)), (torch.bfloat16, (1, 3, 96, 128)), (torch.float16, (1, 3, 640, 640))])
+def test_fused_1x1_and_stride2_layer_give_the_same_bits(dtype, shape):
+    """LP_VARIANT_FUSED_PW_S2: BiFusion's downsample(cv2(x)) -- a 1x1 layer and the 3x3 stride-2 layer behind it -- as one kernel
+    (the 1x1 output stays in LDS): same prediction bits as the two launches."""
+    import ctypes
+    from yolov6.hip import runtime, abi
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG('yololps'), width=0.5, sigma=1.0).cuda().to(dtype)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(93)).cuda().to(dtype)
+    with torch.no_grad():
+        eng = runtime.engine_for(m)
+        eng.autotune = False
+        base = eng.forward(x).clone()
+        took = []
+        for op in range(eng.lib.lp_engine_num_ops(eng.h)):
+            try:
+                eng.set_variant(op, abi.LP_VARIANT_FUSED_PW_S2, 3)
+                took.append(op)
+            except RuntimeError:
+                pass
+        assert len(took) >= 1                                   # the 64-channel pair at the highest resolution of the neck
+        cfg, nb = ctypes.c_int(), ctypes.c_int()
+        abi.check(eng.lib.lp_engine_op_variant(eng.h, took[0], ctypes.byref(cfg), ctypes.byref(nb)), 'lp_engine_op_variant')
+        assert cfg.value == abi.LP_VARIANT_FUSED_PW_S2
+        assert torch.equal(eng.forward(x), base)
+
+
 def test_inflight_pipeline_matches_single_engine():
     """Several batches in flight (yolov6/core/pipeline.py): every batch gets the bits a single engine gives it, the
     other engines take over the first engine's tuning, and the results do not depend on the interleaving."""

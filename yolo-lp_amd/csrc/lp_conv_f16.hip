@@ -5,6 +5,7 @@
 #include "lp_conv3x3_pipe.inc"
 #include "lp_stem_planar.inc"
 #include "lp_stem2_fused.inc"
+#include "lp_pw_s2_fused.inc"
 
 namespace lp {
 int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
@@ -16,6 +17,7 @@ int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
 int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_rows_launch_dtype<f16>(a, cb_pack, st); }
 int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) {
     if (pcfg == PIPE_FUSED2) return stem2_fused_launch<f16>(a, ncu, st);
+    if (pcfg == PIPE_FUSED_PW) return pw_s2_fused_launch<f16>(a, ncu, st);
     return pcfg == PIPE_P ? stem_planar_launch<f16>(a, ncu, st) : pipe_launch_dtype<f16>(pcfg, a, ncu, st);
 }
 }  // namespace lp

@@ -51,6 +51,8 @@ struct Op {
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
     size_t det_scratch = (size_t)-1;    // OP_HEAD_CLS whose detections-only form needs a prediction scratch: its arena offset (after bind)
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
+    int fused_pw = 0;                   // 3x3 stride-2 layer behind a 1x1 layer (BiFusion's downsample(cv2(x))): != 0: the two run as ONE kernel
+                                        // (lp_pw_s2_fused.inc; fused_pw - 1 = its tile choice); the 1x1 op before it is then skipped
     int fused = 0;                      // ERBlock_2[0] (op 2) only: != 0: when the caller's frame has the engine's dtype, input op, stem and this
                                         // layer run as ONE kernel (lp_stem2_fused.inc; fused - 1 = its tile choice)
     int planar = 0;                     // stem over the space-to-depth image only: != 0: when the caller's frame has the engine's dtype, the
@@ -111,7 +113,8 @@ struct lp_engine {
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
     Launch stem_planar;               // ops[1] as the PIPE_P kernel (valid when ops[1].planar)
     Launch stem2_fused;               // ops[0..2] as the fused kernel (valid when ops[2].fused)
-    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar, fused}
+    std::map<int, Launch> pw_fused;   // op index of the 3x3 layer -> the fused 1x1 + 3x3 launch (valid when that op's fused_pw)
+    std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar, fused, fused_pw}
 };
 
 struct lp_engine;
@@ -581,7 +584,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; e->ops[i].fused = it->second[i][8]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; e->ops[i].fused = it->second[i][8]; e->ops[i].fused_pw = it->second[i][9]; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -758,6 +761,27 @@ static int prepare_op(lp_engine* e, size_t idx) {
         fa.fz_c1 = e->tensors[stem.dst].cs;
         F.pipe = PIPE_FUSED2 + 1;
     }
+    if (op.fused_pw) {                  // the 1x1 layer before this one + this layer as one kernel
+        const Op& pw = e->ops[idx - 1];
+        Launch& F = e->pw_fused[(int)idx];
+        F = L;
+        ConvArgs& fa = F.a;
+        int hp = 0;
+        if (!stem2_fused_tile(fa.Ho, fa.Wo, op.fused_pw - 1, &fa.TH, &fa.TW, &hp))
+            return fail(LP_ERR_UNSUPPORTED, "fused 1x1 + 3x3 s2: no tile for this map size");
+        fa.hpitch = hp;
+        fa.tw_magic = (unsigned)(((1u << 22) + fa.TW - 1) / fa.TW);
+        fa.hp_magic = (unsigned)(((1u << 22) + fa.hpitch - 1) / fa.hpitch);
+        fa.tiles_x = ceil_div(fa.Wo, fa.TW);
+        fa.tiles_y = ceil_div(fa.Ho, fa.TH);
+        fa.src[0].ptr = tptr(pw.src[0]);
+        fa.src[0].cs = e->tensors[pw.src[0]].cs;
+        fa.fz_w1 = e->dev_w + pw.w_off;
+        fa.fz_b1 = (const float*)(e->dev_w + pw.b_off);
+        fa.fz_act1 = pw.act;
+        fa.fz_c1 = e->tensors[pw.dst].cs;
+        F.pipe = PIPE_FUSED_PW + 1;
+    }
     return LP_OK;
 }
 
@@ -784,6 +808,26 @@ static bool stem2_fused_possible(const lp_engine* e) {
         const Op& o = e->ops[i];
         for (int k = 0; k < o.nsrc; ++k) if (o.src[k] == s.dst) return false;
         if (o.res == s.dst) return false;
+    }
+    return true;
+}
+// A 1x1 layer (64 stored input channels, <= 64 output channels) whose only reader is the 3x3 stride-2 layer (<= 64 output
+// channels) right behind it on the same lane: BiFusion's downsample(cv2(x)).  `i` = index of the 3x3 layer.
+static bool pw_fused_possible(const lp_engine* e, size_t i) {
+    if (e->dtype == LP_F32 || i < 2 || i >= e->ops.size()) return false;
+    const Op& p = e->ops[i - 1];
+    const Op& c = e->ops[i];
+    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.res >= 0 || c.mode != MODE_ACT || c.nct != 1 || c.nphase != 1) return false;
+    if (p.kind != OP_CONV || p.ksize != 1 || p.stride != 1 || p.nsrc != 1 || p.res >= 0 || p.mode != MODE_ACT || p.nct != 1 || p.nphase != 1 ||
+        p.nchunks != 1 || p.dst != c.src[0] || p.lane != c.lane || p.signal) return false;
+    const int cs0 = e->tensors[p.src[0]].cs, cs1 = e->tensors[p.dst].cs, cs2 = e->tensors[c.dst].cs;
+    if (cs0 != 64 || (cs1 != 32 && cs1 != 64) || (cs2 != 32 && cs2 != 64)) return false;
+    if (conv_shape(e->dtype, p.cfg, 1, 1).CB != cs1 || conv_shape(e->dtype, c.cfg, 3, 2).CB != cs2 || c.nchunks != cs1 / 16) return false;
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+        if (k == i) continue;
+        const Op& o = e->ops[k];
+        for (int q = 0; q < o.nsrc; ++q) if (o.src[q] == p.dst) return false;
+        if (o.res == p.dst) return false;
     }
     return true;
 }
@@ -843,6 +887,8 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
         return pool_launch(tptr(op.src[0]), tptr(op.dst), tptr(op.dst2), tptr(op.dst3), dt, e->B, t.h, t.w, t.cs, st);
     }
     const Launch& L = e->launches[idx];
+    if (idx + 1 < e->ops.size() && e->ops[idx + 1].fused_pw) return LP_OK;   // this 1x1 layer runs inside the fused kernel of the next op
+    if (op.fused_pw) return conv_pipe_launch(dt, PIPE_FUSED_PW, e->pw_fused[(int)idx].a, st);
     if (idx == 1 && stem2_fused_now(e, x, x_dtype)) return LP_OK;            // runs inside the fused kernel of op 2
     if (idx == 2 && stem2_fused_now(e, x, x_dtype)) {
         ConvArgs a = e->stem2_fused.a;
@@ -1054,6 +1100,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     if (rc) return rc;
     if (reps < 1) reps = 3;
     hipStream_t st = (hipStream_t)stream;
+    for (Op& op : e->ops) { op.planar = 0; op.fused = 0; op.fused_pw = 0; }   // every op runs on its own while it is tuned
     rc = forward_single_lane(e, x, x_dtype, pred, st);
     if (rc) return rc;
     struct EventPair {      // destroyed on every return path
@@ -1169,6 +1216,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         op.pipe = best_pipe;
         op.planar = 0;
         op.fused = 0;
+        op.fused_pw = 0;
         rc = prepare_op(e, i);
         if (rc) return rc;
         // the stem may read the caller's frame itself and make the input op unnecessary: worth it if it beats the two together
@@ -1230,9 +1278,43 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             rc = prepare_op(e, i);
             if (rc) return rc;
         }
+        // a 1x1 layer + this 3x3 stride-2 layer as one kernel: against the two ops as tuned
+        if (pw_fused_possible(e, i) && !getenv("LP_NO_FUSED_PW")) {
+            auto time_pair = [&](size_t first) -> float {
+                float ms_min = -1.f;
+                for (int round = 0; round < 3 && trc == LP_OK; ++round) {
+                    float ms = 0.f;
+                    if (hipEventRecord(e0, st) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    for (int r = 0; r < reps; ++r)
+                        for (size_t k = first; k <= i; ++k) run_op(e, k, x, x_dtype, pred, st);
+                    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+                }
+                return ms_min;
+            };
+            op.fused_pw = 0;
+            const float t_sep = time_pair(i - 1);
+            int best_f = 0, last_th = -1, last_tw = -1;
+            float best_fms = -1.f;
+            for (int tile = 0; tile < 3 && trc == LP_OK && t_sep >= 0.f; ++tile) {
+                op.fused_pw = tile + 1;
+                if (prepare_op(e, i) != LP_OK) continue;
+                const ConvArgs& fa = e->pw_fused[(int)i].a;
+                if (fa.TH == last_th && fa.TW == last_tw) break;
+                last_th = fa.TH;
+                last_tw = fa.TW;
+                if (run_op(e, i, x, x_dtype, pred, st) != LP_OK) continue;
+                const float ms = time_pair(i);
+                if (ms >= 0.f && (best_fms < 0.f || ms < best_fms)) { best_fms = ms; best_f = tile + 1; }
+            }
+            if (trc) return fail(trc, "autotune: event timing failed");
+            op.fused_pw = (best_f && best_fms < t_sep) ? best_f : 0;
+            rc = prepare_op(e, i);
+            if (rc) return rc;
+        }
     }
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar, op.fused});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar, op.fused, op.fused_pw});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -1252,7 +1334,7 @@ extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
             for (size_t i = 0; i < dst->ops.size(); ++i) {
                 Op& op = dst->ops[i];
                 op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
-                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7]; op.fused = it->second[i][8];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7]; op.fused = it->second[i][8]; op.fused_pw = it->second[i][9];
                 int rc = prepare_op(dst, i);
                 if (rc) return rc;
             }
@@ -1274,6 +1356,15 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
+    if (cfg == LP_VARIANT_FUSED_PW_S2) {          // the 1x1 layer before this 3x3 stride-2 layer + this layer as one kernel
+        if (!pw_fused_possible(e, (size_t)op_idx) || nbuf != 3)
+            return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: no 1x1 layer of at most 64 channels feeds this 3x3 stride-2 layer alone");
+        op.fused_pw = 1;
+        e->tuned.erase({e->B, e->H, e->W});
+        if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
+    op.fused_pw = 0;
     if (cfg == LP_VARIANT_FUSED_STEM2) {          // stem + this layer as one kernel: on top of whatever variants run for other frame dtypes
         if (op_idx != 2 || !stem2_fused_possible(e) || nbuf != 3)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: only the layer behind the stem (3x3 stride 2, <= 64 channels) has the fused form");
@@ -1321,6 +1412,11 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;
+    if (e->ops[op].fused_pw) {
+        if (cfg) *cfg = LP_VARIANT_FUSED_PW_S2;
+        if (nbuf) *nbuf = 3;
+        return LP_OK;
+    }
     if (e->ops[op].fused) {
         if (cfg) *cfg = LP_VARIANT_FUSED_STEM2;
         if (nbuf) *nbuf = 3;

@@ -45,7 +45,8 @@ enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C =
 
 // Pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc): workgroup configurations
 enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
-                 PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/ };
+                 PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
+                 PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/ };
 
 struct ConvSrc {
     const void* ptr;
