@@ -27,7 +27,7 @@ def last_values(d, counter, n):
     vals = []
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k or 'stem_planar_kernel' in k or 'stem2_fused_kernel' in k):
+        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k or 'stem_planar_kernel' in k or 'stem2_fused_kernel' in k or 'pw_s2_fused_kernel' in k):
             vals.append(float(r['Counter_Value']))
     return vals[-n:]
 
