@@ -228,7 +228,7 @@ bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch)
     std::vector<Cand> cands;
     for (int tw = 2; tw <= 128 && tw < Wo + 2; tw += 2)
         for (int th = 1; th <= 128 / tw && th <= Ho; ++th) {
-            const int hp4 = tw / 2 + 2, rin = 2 * th + 3, hps = 2 * tw + 2;
+            const int hp4 = tw / 2 + 2, rin = 2 * th + 3, hps = 2 * tw + 1;
             const int ntb = (th * tw + 31) / 32;                      // x cout blocks (1 or 2): 2 or 4 stores per wave only up to 8 / 16 tiles
             if ((rin * 6 + 2) * hp4 * 16 > 21 * 1024 || (rin * 6 * hp4 + 63) / 64 > 24 || (2 * th + 1) * hps > 640 || ntb * 2 > 16) continue;
             cands.push_back({(long long)ceil_div(Ho, th) * ceil_div(Wo, tw) * (2 * th + 1) * hps, th, tw});
@@ -237,7 +237,7 @@ bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch)
     if (choice < 0 || choice >= (int)cands.size()) return false;
     *TH = cands[choice].th;
     *TW = cands[choice].tw;
-    *hpitch = 2 * cands[choice].tw + 2;
+    *hpitch = 2 * cands[choice].tw + 1;      // no padding slots: only the last MFMA tile of stage A has positions to zero
     return true;
 }
 
