@@ -801,7 +801,7 @@ static bool stem2_fused_possible(const lp_engine* e) {
     const Op& s = e->ops[1];
     const Op& c = e->ops[2];
     if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.src[0] != s.dst || c.res >= 0 || c.mode != MODE_ACT ||
-        c.nct != 1 || c.nphase != 1 || c.nchunks < 1 || c.nchunks > 2) return false;
+        c.nct != 1 || c.nphase != 1 || c.nchunks < 1 || c.nchunks > 2 || s.act != LP_ACT_RELU || c.act != LP_ACT_RELU) return false;
     const int cb = conv_shape(e->dtype, c.cfg, 3, 2).CB, cs2 = e->tensors[c.dst].cs;
     if ((cb != 32 && cb != 64) || cb != 32 * ((cs2 + 31) / 32) || e->tensors[s.dst].cs > 16 * c.nchunks) return false;
     for (size_t i = 3; i < e->ops.size(); ++i) {
