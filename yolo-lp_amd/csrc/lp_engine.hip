@@ -657,8 +657,10 @@ static bool stream_fits(const lp_engine* e, const Op& op, int wc) {
 static bool rows_fits(const lp_engine* e, const Op& op) {
     if (op.kind != OP_HEAD_CLS) return false;
     const int kc = 128 / (int)dtype_size(e->dtype);
-    for (int i = 0; i < op.nsrc; ++i)
-        if (e->tensors[op.src[i]].cs % kc != 0) return false;
+    for (int i = 0; i < op.nsrc; ++i) {                     // whole K-chunks, or one partial chunk of whole 16-channel K-steps (32-channel towers)
+        const int cs = e->tensors[op.src[i]].cs;
+        if (cs % kc != 0 && !(cs < kc && cs % (kc / 4) == 0)) return false;
+    }
     return head_rows_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
 }
 
