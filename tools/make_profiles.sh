@@ -32,7 +32,7 @@ import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$1', 'value', d['value'], 'value_inflight1', d['value_inflight1'], 'ms_per_step', d['ms_per_step'], '3x3 TFLOP/s', r['achieved'], 'forward_device_ms', r['forward_device_ms'], 'nms_device_ms', r['nms_device_ms'], 'step_ms_inflight1', d['step_ms_inflight1'])"; }
 : > $out/secondary_configs.txt
 timeout -k 10 300 python3 $root/bench.py --model yololpn --batch 128 --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | sec "yololpn 640 bs128 f16 (detections-only forward)" >> $out/secondary_configs.txt
-timeout -k 10 300 python3 $root/bench.py --model yololpn --batch 128 --steps 30 --warmup 3 --no-cpu-baseline --via-pred 2>/dev/null | sec "yololpn 640 bs128 f16 (--via-pred)" >> $out/secondary_configs.txt
+timeout -k 10 300 python3 $root/bench.py --model yololpn --batch 128 --steps 30 --warmup 12 --no-cpu-baseline --via-pred 2>/dev/null | sec "yololpn 640 bs128 f16 (--via-pred)" >> $out/secondary_configs.txt
 timeout -k 10 400 python3 $root/bench.py --model yolov6m --batch 8 --size 1280 --dtype bf16 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | sec "yolov6m 1280 bs8 bf16 (detections-only forward)" >> $out/secondary_configs.txt
 timeout -k 10 300 python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --via-pred 2>/dev/null | sec "yololps 640 bs32 f16 (--via-pred)" >> $out/secondary_configs.txt
 echo done; ls $out
