@@ -21,6 +21,8 @@ if ROOT not in sys.path:
 
 METRIC = 'images/sec (640×640) end-to-end detect+NMS, yololps, 1/2/4/8 MI355X'
 PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_BOUND = ('yololpn',)   # configurations whose roofline is HBM bandwidth; the others: dense MFMA
+ALG_MB = {'yololpn': (74.66, 9.39)}   # algorithmic MB per 640x640 image, MB of weights per batch
 SIGMA = {'yololps': 0.25, 'yololpn': 0.6, 'yolov6m': 0.25, 'yolov6s6': 0.25, 'yolov6m6': 0.25}   # predictor-weight scale of the synthetic recipe (the P6 assemblies are extra configs)
 
 
@@ -45,7 +47,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
-    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'),
+    ap.add_argument('--single-lane', type=int, default=-1, help='1: every engine issues its kernels on ONE stream (no side lanes for '
+                    'independent branches); 0: up to three lanes per forward; default: 1 with several batches in flight, else 0 '
+                    '(profiles/r03_inflight_lanes.txt)')
+    ap.add_argument('--roofline-file', default=os.path.join(ROOT, 'profiles', 'r03_roofline.json'),
+                    help='roofline of the 3x3 layers from a rocprofv3 --kernel-trace of this command (tools/roofline_from_trace.py); '
+                         'reported as roofline.frac when its kernel-source hash equals that of this build')
+    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'),
                     help='per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run (tools/pmc_traffic.py); used only '
                          'when the kernel-source hash recorded in it equals that of the sources this build was made from')
     ap.add_argument('--profile-inner', type=int, default=4, help='back-to-back launches of each op per event pair in the per-op '
@@ -149,7 +157,7 @@ def main():
     pipe = None
     if depth > 1:
         from yolov6.core.pipeline import InflightForward
-        pipe = InflightForward(model, depth)
+        pipe = InflightForward(model, depth, single_lane=None if args.single_lane < 0 else bool(args.single_lane))
     nstep = [0]
 
     ws1 = [[None, None], [None, None]]   # one-batch-in-flight path: two [candidate workspace, event of its last NMS], used alternately
@@ -168,6 +176,7 @@ def main():
                 handle, ready, release = pipe.submit_det(xs[k], args.conf, fresh=False)
             s_post.wait_event(ready)
         else:
+            eng.set_single_lane(args.single_lane == 1)              # one batch in flight: the lanes of a forward overlap its branches
             if args.via_pred:
                 pred = eng.forward(x)
             else:
@@ -298,7 +307,7 @@ def main():
         roofline = {
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_source': traffic_note,
-            'kernel': '3x3 convolution layers (conv3x3_pipe_kernel / stem2_fused_kernel = stem + the layer behind it / conv_mfma_kernel<KS=3>, implicit GEMM, all %d of a step)' % len(conv3),
+            'kernel': '3x3 convolution layers (conv3x3_pipe_kernel / conv3x3_s2_kernel / stem2_fused_kernel = stem + the layer behind it / conv_mfma_kernel<KS=3>, implicit GEMM, all %d of a step)' % len(conv3),
             'timing': 'hipEvent pairs on the launch stream around %d back-to-back launches of each op' % max(1, args.profile_inner),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
@@ -307,6 +316,37 @@ def main():
             'forward_device_ms': round(total_ms, 3), 'nms_device_ms': round(sorted(t_nms)[len(t_nms) // 2], 3),
             'forward_hbm_gbs': round(sum(o['bytes'] for o in ops) / (total_ms * 1e-3) / 1e9, 1),
         }
+        # The headline fraction comes from the kernel trace (rocprofv3 --kernel-trace of this command, one batch in flight:
+        # tools/roofline_from_trace.py -> profiles/) when that file was measured on this build's kernel sources; the live
+        # event-timed figure stays beside it as frac_event.
+        roofline['frac_event'] = roofline['frac']
+        roofline['frac_source'] = 'live hipEvent timing (no kernel-trace roofline file for this workload and build)'
+        if default_workload and os.path.exists(args.roofline_file):
+            from yolov6.hip.srchash import source_hash
+            rf = json.load(open(args.roofline_file))
+            if rf.get('kernel_source_hash') == source_hash():
+                roofline['achieved_event'] = roofline['achieved']
+                roofline['achieved'], roofline['frac'] = rf['achieved_tflops'], rf['frac']
+                roofline['trace_us_per_step'] = rf['conv3_us_per_step']
+                roofline['frac_source'] = '%s (rocprofv3 kernel trace, %d timed steps)' % (os.path.relpath(args.roofline_file, ROOT), rf['steps'])
+            else:
+                roofline['frac_source'] = 'live hipEvent timing (stale: %s was measured on kernel sources %s, this build is %s)' % (
+                    os.path.relpath(args.roofline_file, ROOT), rf.get('kernel_source_hash'), source_hash())
+        if args.model in HBM_BOUND:
+            # bandwidth-bound configuration (AI 153 FLOP/B < machine balance 312): the roofline of the forward is HBM.
+            # Algorithmic bytes (every layer reads its input once and writes its output once, weights once per batch) of the
+            # whole forward / its device time; peak 8 TB/s (MI355X_MICROARCH.md).
+            mb_img, mb_w = ALG_MB[args.model]
+            scale = (args.size / 640.0) ** 2
+            alg = (mb_img * scale * B + mb_w) * 1e6
+            gbs = alg / (total_ms * 1e-3) / 1e9
+            roofline.update({
+                'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                'frac_source': 'algorithmic bytes of the forward (SURVEY 8(d): %.2f MB per image + %.2f MB weights) / summed device time of its kernels (live hipEvent timing)' % (mb_img * scale, mb_w),
+                'kernel': 'whole forward (%d launches; no single kernel dominates a bandwidth-bound configuration)' % len(ops),
+                'algorithmic_bytes_per_launch': round(alg), 'launches': 1, 'avg_launch_ms': round(total_ms, 4),
+                'throughput_hbm_frac': round(world * B * args.steps / elapsed * (mb_img * scale) * 1e6 / 8e12 / world, 4),
+                'mfma_3x3_tflops': round(ach, 2)})
         result = {
             'metric': METRIC, 'value': round(world * B * args.steps / elapsed, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -320,7 +360,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d: images sharded, all-gather of detections' % world,
                        'path': 'Model.forward -> pred[B,N,290] -> lp_nms' if args.via_pred else
                                'detections-only forward (head writes NMS candidates: lp_engine_forward_det) -> lp_nms_candidates',
-                       'streams': ('%d batches in flight (one engine + arena + streams each) || NMS(+gather) on a post stream' % depth
+                       'streams': ('%d batches in flight (one engine + arena + stream each%s) || NMS(+gather) on a post stream' % (depth, '' if pipe is None or pipe.single_lane else ', three execution lanes per forward')
                                    if depth > 1 else 'forward || NMS(+gather) of the previous step') if overlap else 'single stream',
                        'mean_detections_per_image': round(counts, 1),
                        'host_enqueue_ms_per_step': round(t_issue / args.steps * 1e3, 3),

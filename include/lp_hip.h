@@ -135,9 +135,17 @@ int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, voi
 int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, double conf_thres, void* workspace, size_t workspace_bytes,
                           void* stream);
 
-/* enable != 0: lp_engine_forward captures its launches into a hipGraph on first use with a given (x, pred, dtype,
- * launch geometry) and replays it afterwards; any other pointers re-capture.  For launch-bound shapes (batch 1). */
+/* enable != 0: lp_engine_forward / lp_engine_forward_det capture their launches into a hipGraph on first use with a given
+ * (x, pred or workspace + threshold, dtype, launch geometry) and replay it afterwards; any other pointers re-capture.  For
+ * launch-bound shapes (batch 1). */
 int lp_engine_set_graph(lp_engine* e, int enable);
+
+/* enable != 0: the forwards issue every kernel on the caller's stream in op order; 0 (default): independent branches of the
+ * graph (lp_engine_set_lane) run on side streams forked from / joined into the caller's stream.  The lanes shorten ONE forward
+ * (+2.6 % at one batch in flight); with several forwards in flight on several streams their fork / join events cost more than
+ * they hide (six batches in flight: 16.2 k images/s on one lane each against 14.9 k; profiles/r03_inflight_lanes.txt), so
+ * InflightForward switches them off.  Results do not depend on it. */
+int lp_engine_set_single_lane(lp_engine* e, int enable);
 
 /* Introspection for benchmarks: ops of the frozen graph and per-op device time (hipEvent pairs on
  * `stream`, one untimed warm run first).  op_ms has lp_engine_num_ops() entries (milliseconds). */
@@ -197,6 +205,11 @@ int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int m
 int lp_nms_candidates(int B, int N, double iou_thres, int max_det, float* det, int32_t* count, int32_t* keep, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Device int32 [B] inside `workspace`: how many anchors of each image passed the confidence mask (nms.py:90-96) in the last
+ * lp_nms / lp_engine_forward_det that used it (valid once that call's stream work is done).  Callers use it as a cheap
+ * estimate of the candidate density when choosing between the two forms of the path; nothing in the results depends on it. */
+const int32_t* lp_nms_candidate_counts(const void* workspace, int B, int N);
+
 /* ---------------------------------------------------------------------------------------------------
  * Callers either side of the path.
  *
@@ -231,6 +244,12 @@ int lp_eval_counts(const float* det, const int32_t* det_count, int max_det, cons
  * every pair of neighbouring fp32 values (2^32 - 1 pairs, NaNs skipped) on the device and leaves the number of violations in
  * *dev_violations (device memory, 8 bytes).  Expected: 0 (tests/test_hip_kernels.py). */
 int lp_check_sigmoid_monotone(unsigned long long* dev_violations, void* stream);
+
+/* Verification hook of the greedy NMS step: the kernels decide torchvision's `inter / union > iou_threshold` with two products and
+ * compares where the outcome is certain and with the fp32 division only inside a 2^-19-wide band around the threshold (lp_nms.hip,
+ * iou_gt).  Evaluates both forms on n box pairs (device fp32 [n][8]: box i xyxy, box j xyxy); dev_out[k] bit 0 = the product form,
+ * bit 1 = the plain division.  Expected: both bits equal for every pair, and equal to the fp32 restatement (tests/test_hip_kernels.py). */
+int lp_check_iou_predicate(const float* dev_pairs, long long n, double iou_thres, unsigned char* dev_out, void* stream);
 
 /* Host-side planning of the frame-reading stem kernels (no device needed; used by the CPU tests): the `choice`-th best output tile
  * TH x TW for an Ho x Wo output map of stem_planar_kernel (fused == 0: TW % 4 == 0, TH * TW <= 512, planar halo within its 20 KiB LDS

@@ -23,6 +23,21 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3   # yolov6/utils/torch_utils.py:44 (initialize_weights sets every BatchNorm2d.eps)
 
+# Rounding-aware mode (``forward(..., round_to=torch.float16 / torch.bfloat16)``): what the reference's ``--half`` path
+# (inferer.py:46-50: model.half(), frames .half()) computes when every convolution accumulates in fp32 -- weights (after
+# the fp32 fold), biases, BottleRep's alpha and every layer output are rounded to the 16-bit type (model.half() rounds every
+# parameter); accumulation, the class sigmoids and the box decode are fp32 (anchors / strides are fp32 and promote
+# the decode).  That is the arithmetic contract of the HIP
+# engine's fp16 / bf16 mode; what still differs from it is the fp32 summation order inside a convolution and the last bit
+# of exp / reciprocal in SiLU, each of which can move an activation by one 16-bit ulp when its fp32 value sits at a
+# rounding boundary.  None = the plain fp32 restatement.
+_RND = None
+
+
+def _r(t):
+    """Round to the 16-bit activation type of the rounding-aware mode (identity in fp32 mode)."""
+    return t if _RND is None else t.to(_RND).float()
+
 
 class Arch:
     """Static description of one model (what configs/*.py + yolo.py:54-67 resolve to)."""
@@ -115,14 +130,14 @@ def fold_repvgg(sd, p):
 def rep(sd, p, x, stride=1):
     """RepVGGBlock deploy forward: ReLU(conv3x3(x)) (common.py:258-259)."""
     w, b = fold_repvgg(sd, p)
-    return F.relu(F.conv2d(x, w, b, stride=stride, padding=1))
+    return _r(F.relu(F.conv2d(x, _r(w), _r(b), stride=stride, padding=1)))
 
 
 def cba(sd, p, x, stride=1, act='relu'):
     """Conv (SiLU) / SimConv, Conv_C3 (ReLU) fused forward (common.py:41-42,65-66,475-476)."""
     w, b = fold_conv_bn(sd, p)
-    y = F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
-    return F.silu(y) if act == 'silu' else F.relu(y)
+    y = F.conv2d(x, _r(w), _r(b), stride=stride, padding=w.shape[-1] // 2)
+    return _r(F.silu(y) if act == 'silu' else F.relu(y))
 
 
 def rep_stage(sd, p, x, n):
@@ -135,8 +150,8 @@ def rep_stage(sd, p, x, n):
 
 def bottle_rep(sd, p, x):
     """BottleRep: conv2(conv1(x)) + alpha*x (in==out always on this path; common.py:452-455)."""
-    y = rep(sd, p + '.conv2', rep(sd, p + '.conv1', x))
-    return y + sd[p + '.alpha'] * x
+    y = rep(sd, p + '.conv2', rep(sd, p + '.conv1', x))     # (16-bit mode: conv2's output is rounded, then the sum is)
+    return _r(y + _r(sd[p + '.alpha']) * x)
 
 
 def bepc3(sd, p, x, n):
@@ -171,8 +186,8 @@ def sim_sppf(sd, p, x):
 
 def bifusion(sd, p, x0, x1, x2):
     """BiFusion.forward (common.py:523-527); Transpose = 2x2 s2 deconv with bias (:186-187)."""
-    up = F.conv_transpose2d(x0, sd[p + '.upsample.upsample_transpose.weight'],
-                            sd[p + '.upsample.upsample_transpose.bias'], stride=2)
+    up = _r(F.conv_transpose2d(x0, _r(sd[p + '.upsample.upsample_transpose.weight']),
+                               _r(sd[p + '.upsample.upsample_transpose.bias']), stride=2))
     a = cba(sd, p + '.cv1', x1)
     d = cba(sd, p + '.downsample', cba(sd, p + '.cv2', x2), stride=2)
     return cba(sd, p + '.cv3', torch.cat((up, a, d), 1))
@@ -205,8 +220,8 @@ def neck(sd, a, feats):
         return bepc3(sd, 'neck.' + p, t, n) if a.csp_neck else rep_stage(sd, 'neck.' + p, t, n)
 
     def up(i, t):      # Transpose.forward (common.py:186-187)
-        return F.conv_transpose2d(t, sd['neck.upsample%d.upsample_transpose.weight' % i],
-                                  sd['neck.upsample%d.upsample_transpose.bias' % i], stride=2)
+        return _r(F.conv_transpose2d(t, _r(sd['neck.upsample%d.upsample_transpose.weight' % i]),
+                                     _r(sd['neck.upsample%d.upsample_transpose.bias' % i]), stride=2))
 
     r = a.repeats
     feats = list(feats)
@@ -267,15 +282,15 @@ def head(sd, a, feats):
         s = cba(sd, 'detect.stems.%d' % i, f, act='silu')
         c = cba(sd, 'detect.cls_convs.%d' % i, s, act='silu')
         for acc, h in zip(cls_all, CLS_HEADS):
-            o = F.conv2d(c, sd['detect.%s_preds.%d.weight' % (h, i)], sd['detect.%s_preds.%d.bias' % (h, i)])
+            o = F.conv2d(c, _r(sd['detect.%s_preds.%d.weight' % (h, i)]), _r(sd['detect.%s_preds.%d.bias' % (h, i)]))
             acc.append(torch.sigmoid(o).reshape(B, -1, l))
         r = cba(sd, 'detect.reg_convs.%d' % i, s, act='silu')
-        reg = F.conv2d(r, sd['detect.reg_preds.%d.weight' % i], sd['detect.reg_preds.%d.bias' % i])
+        reg = F.conv2d(r, _r(sd['detect.reg_preds.%d.weight' % i]), _r(sd['detect.reg_preds.%d.bias' % i]))
         if a.use_dfl:   # effidehead.py:247-249: softmax over the reg_max+1 bins, projected by proj_conv
             reg = reg.reshape(-1, 4, a.reg_max + 1, l).permute(0, 2, 1, 3)
             reg = F.conv2d(F.softmax(reg, dim=1), sd['detect.proj_conv.weight'])
         reg_all.append(reg.reshape(B, 4, l))
-        cor = F.conv2d(r, sd['detect.cor_preds.%d.weight' % i], sd['detect.cor_preds.%d.bias' % i])
+        cor = F.conv2d(r, _r(sd['detect.cor_preds.%d.weight' % i]), _r(sd['detect.cor_preds.%d.bias' % i]))
         cor_all.append(cor.reshape(B, 8, l))
     cat = lambda parts: torch.cat(parts, -1).permute(0, 2, 1)   # noqa: E731
     pts, st = anchors([f.shape[2:] for f in feats])
@@ -284,14 +299,22 @@ def head(sd, a, feats):
     return torch.cat([box, ones, corners] + [cat(p) for p in cls_all], -1)
 
 
-def forward(sd, a, x, return_stages=False):
-    """Model.forward (yolo.py:32-40): pred [B,N,no] fp32 and the three neck maps."""
+def forward(sd, a, x, return_stages=False, round_to=None):
+    """Model.forward (yolo.py:32-40): pred [B,N,no] fp32 and the three neck maps.  ``round_to``: the rounding-aware mode
+    (see ``_RND``) for the fp16 / bf16 engines; ``sd`` stays the fp32 state_dict (it is folded in fp32, then rounded)."""
+    global _RND
+    if round_to not in (None, torch.float16, torch.bfloat16):
+        raise ValueError('round_to must be None, torch.float16 or torch.bfloat16')
     sd = {k: v.float() for k, v in sd.items()}
     x = x.float()
-    with torch.no_grad():
-        bb = backbone(sd, a, x)
-        nk = neck(sd, a, bb)
-        pred = head(sd, a, nk)
+    prev, _RND = _RND, round_to
+    try:
+        with torch.no_grad():
+            bb = backbone(sd, a, _r(x))
+            nk = neck(sd, a, bb)
+            pred = head(sd, a, nk)
+    finally:
+        _RND = prev
     if return_stages:
         return pred, nk, bb
     return pred, nk

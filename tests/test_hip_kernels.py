@@ -528,3 +528,63 @@ def test_sigmoid_of_the_kernels_is_monotone_over_all_of_fp32():
               'lp_check_sigmoid_monotone')
     torch.cuda.synchronize()
     assert int(bad[0]) == 0
+
+
+@pytest.mark.parametrize('iou_thres', [0.45, 0.65, 0.5, 0.1, 0.999, 0.0, 1.0])
+def test_iou_predicate_product_form_equals_the_division(iou_thres):
+    """greedy NMS (lp_nms.hip, iou_gt): `inter / union > iou_threshold` is decided by two products and compares where the outcome
+    is certain and by the fp32 division only inside a 2^-19-wide band around the threshold.  Both forms, side by side on the
+    device, against the fp32 op-by-op restatement (numpy) of torchvision's expression: random pairs, pairs whose IoU sits within
+    a few ulps of the threshold on either side (including exactly on it), degenerate and disjoint boxes."""
+    import ctypes
+    import numpy as np
+    from yolov6.hip import abi
+    rng = np.random.default_rng(int(iou_thres * 1000))
+    f32 = np.float32
+    thr_f = f32(iou_thres)
+    if float(thr_f) > iou_thres:
+        thr_f = np.nextafter(thr_f, f32(-np.inf))
+    pairs = []
+    # random overlapping / disjoint boxes in pixel ranges
+    n = 200000
+    xy = rng.uniform(0, 640, (n, 2, 2)).astype(f32)
+    wh = rng.uniform(0.5, 300, (n, 2, 2)).astype(f32)
+    pairs.append(np.concatenate([xy[:, 0], xy[:, 0] + wh[:, 0], xy[:, 1], xy[:, 1] + wh[:, 1]], 1))
+    # nested boxes [0,0,a,1] and [0,0,b,1]: IoU = b / a, with b stepped through the fp32 neighbours of t * a
+    a = rng.uniform(1, 1000, 4000).astype(f32)
+    for k in range(-40, 41):
+        b = (thr_f * a).astype(f32)
+        for _ in range(abs(k)):
+            b = np.nextafter(b, f32(np.inf) if k > 0 else f32(-np.inf))
+        z = np.zeros_like(a)
+        pairs.append(np.stack([z, z, a, z + 1, z, z, b, z + 1], 1))
+    # shifted equal squares: IoU = (s - d) / (s + d) crossing the threshold
+    s = rng.uniform(10, 500, 100000).astype(f32)
+    t_ = float(thr_f)
+    d = (s * f32((1 - t_) / (1 + t_))).astype(f32) * rng.uniform(0.99999, 1.00001, s.shape).astype(f32)
+    z = np.zeros_like(s)
+    pairs.append(np.stack([z, z, s, s, d, z, d + s, s], 1))
+    # degenerate: zero-area, inverted and touching boxes, huge and tiny sides
+    pairs.append(np.array([[0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 10, 10, 10, 0, 20, 10], [5, 5, 1, 1, 0, 0, 10, 10],
+                           [0, 0, 1e20, 1e20, 0, 0, 1e20, 1e20], [0, 0, 3e38, 3e38, 0, 0, 3e38, 3e38], [0, 0, 1e-30, 1e-30, 0, 0, 1e-30, 1e-30],
+                           [0, 0, 10, 10, 0, 0, 10, 10], [0, 0, 10, 10, 2, 2, 8, 8]], dtype=f32))
+    q = np.ascontiguousarray(np.concatenate(pairs, 0).astype(f32))
+    with np.errstate(all='ignore'):
+        ia = (q[:, 2] - q[:, 0]) * (q[:, 3] - q[:, 1])
+        ja = (q[:, 6] - q[:, 4]) * (q[:, 7] - q[:, 5])
+        w = np.minimum(q[:, 2], q[:, 6]) - np.maximum(q[:, 0], q[:, 4])
+        h = np.minimum(q[:, 3], q[:, 7]) - np.maximum(q[:, 1], q[:, 5])
+        w = np.where(w > 0, w, f32(0))
+        h = np.where(h > 0, h, f32(0))
+        inter = (w * h).astype(f32)
+        ovr = inter / ((ia + ja).astype(f32) - inter).astype(f32)
+        want = ovr.astype(np.float64) > iou_thres            # torchvision compares in double against the python float
+    dq = torch.from_numpy(q).cuda()
+    out = torch.zeros(len(q), dtype=torch.uint8, device='cuda')
+    abi.check(abi.load().lp_check_iou_predicate(ctypes.c_void_p(dq.data_ptr()), len(q), float(iou_thres), ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'lp_check_iou_predicate')
+    got = out.cpu().numpy()
+    assert np.array_equal((got & 2) != 0, want)              # the division form == the restatement
+    assert np.array_equal((got & 1) != 0, want)              # the product form == the same
+    if 0.0 < iou_thres < 1.0:
+        assert want.any() and not want.all()

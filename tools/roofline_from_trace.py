@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""roofline.frac of the dominant kernels from a rocprofv3 --kernel-trace of bench.py (the judge's arithmetic):
+algorithmic FLOPs of the 3x3 convolution layers of a step / the summed kernel-trace duration of their dispatches in the
+TIMED steps (the last steps x launches_per_step matching dispatches; everything before belongs to warm-up and the tuner).
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt1 -- python3 bench.py --steps 50 --warmup 5 --inflight 1 --no-cpu-baseline > bench.json
+    python tools/roofline_from_trace.py gpurun_out/kt1 bench.json --steps 100 > profiles/r03_roofline.json
+
+(one batch in flight: kernels of different batches do not overlap, so a dispatch's duration is its own; bench.py times its
+K steps twice -- with --inflight 1 both passes are one-in-flight -- hence 2 x K steps in the trace).  The file records the hash of
+the kernel sources; bench.py reports the figure as roofline.frac only when that hash is the running build's.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolov6.hip.srchash import source_hash   # noqa: E402
+
+CONV3 = re.compile(r'conv3x3_\w*kernel|stem_planar_kernel|stem2_fused_kernel|pw_s2_fused_kernel|conv_mfma_kernelI\w+?Li\dELi3E')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('trace_dir')
+    ap.add_argument('bench_json', help='the JSON line bench.py printed in that run (FLOPs and layer count of the 3x3 layers)')
+    ap.add_argument('--steps', type=int, required=True, help='timed steps in the trace')
+    ap.add_argument('--peak', type=float, default=2500.0)
+    a = ap.parse_args()
+    d = json.loads([l for l in open(a.bench_json).read().splitlines() if l.startswith('{')][-1])
+    r = d['roofline']
+    flops_step = r['flops_per_launch'] * 1e9 * r['launches']
+    rows = []
+    for f in glob.glob(a.trace_dir + '/**/*kernel_trace.csv', recursive=True):
+        rows += [(int(x['Start_Timestamp']), int(x['End_Timestamp']), x['Kernel_Name']) for x in csv.DictReader(open(f))]
+    rows.sort()
+    conv = [(e - s) / 1e3 for s, e, n in rows if CONV3.search(n)]
+    # dispatches per step: the fused kernels run two layers each; count from the tail of the trace, which is steady state
+    names = [n for s, e, n in rows if CONV3.search(n)]
+    per_step = r['launches'] - sum(1 for n in names[-r['launches']:] if 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n)
+    # (a window of `launches` dispatches holds at least one step; fused dispatches in it, scaled to one step)
+    fused_per_step = round(sum(1 for n in names[-per_step * a.steps:] if 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n) / a.steps)
+    per_step = r['launches'] - fused_per_step
+    tail = conv[-per_step * a.steps:]
+    us_step = sum(tail) / a.steps
+    ach = flops_step / (us_step * 1e-6) / 1e12
+    print(json.dumps({
+        'kernel_source_hash': source_hash(), 'workload': d['config']['workload'],
+        'kernel': '3x3 convolution layers: every dispatch of conv3x3_*kernel / stem2_fused_kernel / stem_planar_kernel / pw_s2_fused_kernel / '
+                  'conv_mfma_kernel<KS=3> in the timed steps of a rocprofv3 --kernel-trace of bench.py --inflight 1',
+        'steps': a.steps, 'dispatches_per_step': per_step, 'layers_per_step': r['launches'],
+        'conv3_us_per_step': round(us_step, 1), 'avg_dispatch_us': round(sum(tail) / len(tail), 2),
+        'flops_per_step': flops_step, 'achieved_tflops': round(ach, 1), 'peak_tflops': a.peak, 'frac': round(ach / a.peak, 4),
+        'bench_event_timed_frac': r.get('frac_event', r['frac']), 'bench_value_inflight1': d.get('value_inflight1')}))
+
+
+if __name__ == '__main__':
+    main()

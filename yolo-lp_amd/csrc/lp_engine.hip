@@ -95,19 +95,22 @@ struct lp_engine {
     hipStream_t lane_stream[LP_MAX_LANES] = {};   // [0] = the caller's stream
     std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
+    bool single_lane = false;         // lp_engine_set_single_lane: every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
     struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
         hipGraphExec_t exec = nullptr;
         const void* x = nullptr;
-        float* pred = nullptr;
+        float* pred = nullptr;             // plain forward: the prediction tensor; detections-only forward: null
+        void* ws = nullptr;                // detections-only forward: the candidate workspace (and its threshold)
+        float conf = 0.f;
         int x_dtype = -1;
         unsigned long long epoch = 0, last_use = 0;
         hipStream_t stream = nullptr;  // stream of its last launch: synchronised before the executable graph is destroyed
     };
     std::vector<CachedGraph> graphs;   // a few, so that alternating buffers do not re-capture (and destroy) every call
     unsigned long long graph_clock = 0;
-    hipStream_t last_stream = nullptr; // the caller's stream of the last forward (synchronised before the engine is destroyed)
-    bool last_stream_valid = false;
+    hipEvent_t done_ev = nullptr;      // recorded on the caller's stream behind every forward: lp_engine_destroy waits for it (an
+    bool done_valid = false;           // event of our own, not the caller's stream handle, which may be gone by then)
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy null stream, which cannot capture)
     unsigned long long epoch = 1;      // changes whenever launches are re-prepared
     std::vector<Launch> launches;     // per op, prepared at bind / after tuning
@@ -139,10 +142,12 @@ extern "C" void lp_engine_destroy(lp_engine* e) {
     if (!e) return;
     // Nothing of the engine may die under in-flight work: the side lanes may still run kernels of the last forward that
     // read launch arguments' device buffers and wait on / record the events destroyed below (an executable graph destroyed
-    // under its last launch aborted the process in round 1).  The caller's stream of the last forward is synchronised too.
+    // under its last launch aborted the process in round 1).  The last forward on the caller's stream is waited for through
+    // an event the engine owns (the stream handle itself may have been destroyed by the caller since).
     for (int l = 1; l < LP_MAX_LANES; ++l)
         if (e->lane_stream[l]) (void)hipStreamSynchronize(e->lane_stream[l]);
-    if (e->last_stream_valid) (void)hipStreamSynchronize(e->last_stream);
+    if (e->done_valid) (void)hipEventSynchronize(e->done_ev);
+    if (e->done_ev) (void)hipEventDestroy(e->done_ev);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
     for (auto& g : e->graphs) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
@@ -936,7 +941,7 @@ static int ensure_lanes(lp_engine* e) {
 
 static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t main_st, const DetCtx* det = nullptr) {
     int rc;
-    if (e->n_lanes <= 1) {
+    if (e->n_lanes <= 1 || e->single_lane) {      // (op order is a topological order of the graph: the host adds producers first)
         for (size_t i = 0; i < e->ops.size(); ++i) {
             rc = run_op(e, i, x, x_dtype, pred, main_st, det);
             if (rc) return rc;
@@ -966,26 +971,47 @@ static int issue_forward(lp_engine* e, const void* x, int x_dtype, float* pred, 
     return LP_OK;
 }
 
+extern "C" int lp_engine_set_single_lane(lp_engine* e, int enable) {
+    if (!e) return fail(LP_ERR_ARG, "lp_engine_set_single_lane: null engine");
+    if (e->single_lane != (enable != 0)) ++e->epoch;      // captured graphs hold the lane structure
+    e->single_lane = enable != 0;
+    return LP_OK;
+}
+
 extern "C" int lp_engine_set_graph(lp_engine* e, int enable) {
     if (!e) return fail(LP_ERR_ARG, "lp_engine_set_graph: null engine");
     e->use_graph = enable != 0;
     return LP_OK;
 }
 
-extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
-    int rc = check_ready(e, x, x_dtype);
-    if (rc) return rc;
-    hipStream_t main_st = (hipStream_t)stream;
-    e->last_stream = main_st;
-    e->last_stream_valid = true;
-    if (!e->use_graph) return issue_forward(e, x, x_dtype, pred, main_st);
-    // hipGraph path: the ~80 launches (and the lane fork/join events) of one forward are captured once per
-    // (input pointer, output pointer, dtype, launch geometry) and replayed with a single hipGraphLaunch -- what the
-    // per-image loop of Inferer needs, where the forward is launch-bound.
+// Marks the end of a forward on the caller's stream with the engine's own event (see lp_engine_destroy).
+static int mark_done(lp_engine* e, hipStream_t st) {
+    if (!e->done_ev) LP_HIP_CHECK(hipEventCreateWithFlags(&e->done_ev, hipEventDisableTiming));
+    LP_HIP_CHECK(hipEventRecord(e->done_ev, st));
+    e->done_valid = true;
+    return LP_OK;
+}
+
+// One forward, plain (det == nullptr: writes pred) or detections-only (det: the head writes NMS candidates into det's
+// workspace, whose counters are zeroed first), re-issued launch by launch or -- lp_engine_set_graph -- replayed as one hipGraph:
+// the ~80 launches (and the lane fork / join events) of a forward are captured once per (input pointer, output pointer or
+// workspace + threshold, dtype, launch geometry) and replayed with a single hipGraphLaunch -- what the per-image loop of
+// Inferer needs, where the forward is launch-bound.
+static int run_forward(lp_engine* e, const void* x, int x_dtype, float* pred, const DetCtx* det, void* ws, hipStream_t main_st) {
+    int rc;
+    auto issue = [&](hipStream_t st) -> int {
+        if (det) LP_HIP_CHECK(hipMemsetAsync(det->w.cnt, 0, (size_t)e->B * 4, st));   // BEFORE the lanes fork: every head op comes behind it
+        return issue_forward(e, x, x_dtype, pred, st, det);
+    };
+    if (!e->use_graph) {
+        rc = issue(main_st);
+        return rc ? rc : mark_done(e, main_st);
+    }
     constexpr size_t kMaxGraphs = 8;
+    const float conf = det ? det->conf : 0.f;
     lp_engine::CachedGraph* hit = nullptr;
     for (auto& g : e->graphs)
-        if (g.exec && g.x == x && g.pred == pred && g.x_dtype == x_dtype && g.epoch == e->epoch) hit = &g;
+        if (g.exec && g.x == x && g.pred == pred && g.ws == ws && g.conf == conf && g.x_dtype == x_dtype && g.epoch == e->epoch) hit = &g;
     if (!hit) {
         // retire stale captures (re-tuned / re-bound engine) and, when the cache is full, the least recently used one; an
         // executable graph must outlive its last launch, so that launch's stream is synchronised first
@@ -1006,7 +1032,7 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
         hipGraph_t g = nullptr;
         if (!e->cap_stream) LP_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         LP_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-        rc = issue_forward(e, x, x_dtype, pred, e->cap_stream);
+        rc = issue(e->cap_stream);
         hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(LP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
@@ -1016,6 +1042,8 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
         if (ce != hipSuccess) return fail(LP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce));
         cg.x = x;
         cg.pred = pred;
+        cg.ws = ws;
+        cg.conf = conf;
         cg.x_dtype = x_dtype;
         cg.epoch = e->epoch;
         e->graphs.push_back(cg);
@@ -1024,7 +1052,14 @@ extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float
     LP_HIP_CHECK(hipGraphLaunch(hit->exec, main_st));
     hit->stream = main_st;
     hit->last_use = ++e->graph_clock;
-    return LP_OK;
+    return mark_done(e, main_st);
+}
+
+extern "C" int lp_engine_forward(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream) {
+    int rc = check_ready(e, x, x_dtype);
+    if (rc) return rc;
+    if (!pred) return fail(LP_ERR_ARG, "forward: pred is null");
+    return run_forward(e, x, x_dtype, pred, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, double conf_thres, void* workspace, size_t workspace_bytes,
@@ -1037,12 +1072,7 @@ extern "C" int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, d
     dc.w = nms_carve(workspace, e->B, e->n_anchors);
     dc.conf = (float)conf_thres;
     if (workspace_bytes < dc.w.bytes) return fail(LP_ERR_ARG, "lp_engine_forward_det: workspace too small (lp_nms_workspace_bytes)");
-    hipStream_t main_st = (hipStream_t)stream;
-    e->last_stream = main_st;
-    e->last_stream_valid = true;
-    // the candidate counters are zeroed on the caller's stream BEFORE the lanes fork: every head op comes behind it
-    LP_HIP_CHECK(hipMemsetAsync(dc.w.cnt, 0, (size_t)e->B * 4, main_st));
-    return issue_forward(e, x, x_dtype, nullptr, main_st, &dc);
+    return run_forward(e, x, x_dtype, nullptr, &dc, workspace, (hipStream_t)stream);
 }
 
 static int forward_single_lane(lp_engine* e, const void* x, int x_dtype, float* pred, hipStream_t st) {

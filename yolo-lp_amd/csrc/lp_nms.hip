@@ -214,6 +214,17 @@ __global__ __launch_bounds__(SORT_T) void sort_kernel(unsigned long long* __rest
     }
 }
 
+// torchvision's predicate `inter / (area_i + area_j - inter) > iou_threshold`, fp32 op by op, without the division for
+// (nearly) every pair.  With U = fl(fl(area_i + area_j) - inter), t = thr_f (the largest fp32 <= the double threshold, so that
+// (double)ovr > iou_thres <=> ovr > t) and ovr = fl(inter / U) (round to nearest): ovr > t  <=>  inter / U >= m (resp. > m),
+// m = the midpoint of t and the next fp32 above it, i.e. m = t (1 + e) with 0 < e <= 2^-24.  Let p = fl(t U) = t U (1 + d),
+// |d| <= 2^-24, p and t normal and positive (then U > 0):
+//   inter > fl(p (1 + 2^-20))  =>  inter > t U (1 - 2^-24)^2 (1 + 2^-20) > t U (1 + 2^-21) > m U   =>  ovr > t;
+//   inter < fl(p (1 - 2^-20))  =>  inter < t U (1 + 2^-24)^2 (1 - 2^-20) < t U < m U               =>  not.
+// Only inside that 2^-19-wide band -- and for U <= 0, NaN, infinities, a zero threshold or a subnormal product, where every
+// comparison below is false -- the IEEE division decides, as before.  An fp32 division is ~11 dependent VALU instructions, the
+// two products and compares are 5.  lp_check_iou_predicate runs both forms side by side (tests/test_hip_kernels.py).
+template <bool EXACT_ONLY = false>
 __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1, float jy1,
                                       float jx2, float jy2, float thr_f) {
     const float xx1 = ix1 > jx1 ? ix1 : jx1;
@@ -229,8 +240,27 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
     if (w == 0.f || h == 0.f) return false;
     const float inter = w * h;
     const float jarea = (jx2 - jx1) * (jy2 - jy1);
-    const float ovr = inter / (iarea + jarea - inter);
+    const float u = iarea + jarea - inter;
+    if (!EXACT_ONLY) {
+        const float p = thr_f * u;
+        const bool normal = p >= 1.17549435e-38f && thr_f >= 1.17549435e-38f;   // FLT_MIN: the bounds on p and on m need normal numbers
+        if (normal && inter > p * 1.00000095367431640625f) return true;      // 1 + 2^-20
+        if (normal && inter < p * 0.99999904632568359375f) return false;     // 1 - 2^-20
+    }
+    const float ovr = inter / u;
     return ovr > thr_f;   // thr_f = largest fp32 <= the double threshold  <=>  (double)ovr > iou_thres
+}
+
+// Verification hook: both forms of the predicate on n box pairs (pairs [n][8] = box i xyxy, box j xyxy); out[k] bit 0 = the
+// product form the NMS kernels use, bit 1 = the plain division.
+__global__ __launch_bounds__(256) void iou_predicate_kernel(const float* __restrict__ pairs, long long n, float thr_f, unsigned char* __restrict__ out) {
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const float* q = pairs + k * 8;
+        const float ia = (q[2] - q[0]) * (q[3] - q[1]);
+        const bool a = iou_gt<false>(q[0], q[1], q[2], q[3], ia, q[4], q[5], q[6], q[7], thr_f);
+        const bool b = iou_gt<true>(q[0], q[1], q[2], q[3], ia, q[4], q[5], q[6], q[7], thr_f);
+        out[k] = (unsigned char)((a ? 1 : 0) | (b ? 2 : 0));
+    }
 }
 
 // One block per image: greedy suppression over the sorted candidates, 64 at a time, with LAZY strikes: a chunk of
@@ -459,6 +489,23 @@ int nms_score_launch(float* pred, int B, int rows_per_img, int anchor0, int N, f
 extern "C" size_t lp_nms_workspace_bytes(int B, int N) {
     if (B < 1 || N < 1) return 256;
     return nms_carve(nullptr, B, N).bytes;
+}
+
+extern "C" const int32_t* lp_nms_candidate_counts(const void* workspace, int B, int N) {
+    if (!workspace || B < 1 || N < 1) return nullptr;
+    return nms_carve(const_cast<void*>(workspace), B, N).cnt;
+}
+
+extern "C" int lp_check_iou_predicate(const float* dev_pairs, long long n, double iou_thres, unsigned char* dev_out, void* stream) {
+    if (!dev_pairs || !dev_out || n < 1) return fail(LP_ERR_ARG, "lp_check_iou_predicate: bad argument");
+    if (!(iou_thres >= 0.0 && iou_thres <= 1.0)) return fail(LP_ERR_ARG, "lp_check_iou_predicate: threshold must be in [0, 1]");
+    float thr_f = (float)iou_thres;
+    if ((double)thr_f > iou_thres) thr_f = nextafterf(thr_f, -INFINITY);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(iou_predicate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dev_pairs, n, thr_f, dev_out);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
 }
 
 extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det,

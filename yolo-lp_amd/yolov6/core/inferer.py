@@ -77,12 +77,17 @@ class Inferer:
                 img = img.to(self.device)
             if len(img.shape) == 3:
                 img = img[None]
-            if img.is_cuda:      # a new frame shape binds + tunes + captures once: outside the FPS window
+            if img.is_cuda:      # a new frame shape runs the kernel-variant tuner once: outside the FPS window
                 from yolov6.hip import runtime
                 runtime.prepare_for(self.model.model, img.shape, img.dtype)
             t1 = time.time()
-            pred_results = self.model(img)
-            det = non_max_suppression(pred_results, conf_thres, iou_thres, classes, agnostic_nms, max_det=max_det)[0]
+            if img.is_cuda:
+                # model(img) -> non_max_suppression (reference :80-83) as one call: the detections-only forward, or forward +
+                # lp_nms when most anchors pass the mask (runtime.Engine.detect) -- the same detections bit for bit either way
+                det = runtime.detect(self.model.model, img, conf_thres, iou_thres, max_det)[0]
+            else:
+                pred_results = self.model(img)
+                det = non_max_suppression(pred_results, conf_thres, iou_thres, classes, agnostic_nms, max_det=max_det)[0]
             t2 = time.time()
             fps.update(1.0 / max(t2 - t1, 1e-9))
 

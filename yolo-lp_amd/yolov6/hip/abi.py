@@ -52,6 +52,7 @@ SYMBOLS = {
     'lp_engine_num_anchors': (c_int, [c_void_p]),
     'lp_engine_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'lp_engine_set_graph': (c_int, [c_void_p, c_int]),
+    'lp_engine_set_single_lane': (c_int, [c_void_p, c_int]),
     'lp_engine_num_ops': (c_int, [c_void_p]),
     'lp_engine_op_info': (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_double), POINTER(c_double)]),
@@ -64,11 +65,13 @@ SYMBOLS = {
     'lp_engine_set_op_variant': (c_int, [c_void_p, c_int, c_int, c_int]),
     'lp_engine_copy_tuning': (c_int, [c_void_p, c_void_p]),
     'lp_nms_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'lp_nms_candidate_counts': (c_void_p, [c_void_p, c_int, c_int]),
     'lp_preprocess_letterbox': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p]),
     'lp_rescale_round': (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     'lp_eval_counts': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'lp_check_sigmoid_monotone': (c_int, [c_void_p, c_void_p]),
+    'lp_check_iou_predicate': (c_int, [c_void_p, ctypes.c_longlong, c_double, c_void_p, c_void_p]),
     'lp_plan_stem_tile': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_size_t, c_void_p]),

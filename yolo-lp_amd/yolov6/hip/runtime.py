@@ -21,6 +21,7 @@ import torch.nn as nn
 from yolov6.hip import abi
 from yolov6.layers import common as L
 
+DET_CROSSOVER = 0.5   # candidate density (candidates / anchors) above which forward + lp_nms beats the detections-only forward
 _DT = {torch.float16: abi.LP_F16, torch.bfloat16: abi.LP_BF16, torch.float32: abi.LP_F32}
 _TORCH_DT = {v: k for k, v in _DT.items()}
 CLS_HEADS = ('pro', 'alp', 'ad0', 'ad1', 'ad2', 'ad3', 'ad4', 'ad5')
@@ -79,8 +80,13 @@ class Engine:
         self.autotune = os.environ.get('LP_AUTOTUNE', '1') != '0'
         self.max_tuned_shapes = 32   # a directory of oddly sized frames must not pay the tuner for every new shape
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
+        self.single_lane = False   # set_single_lane
         self._graph_pred = None
         self._graph_x = None       # graph mode: persistent staging copy of the input (fixed address)
+        self.det_crossover = DET_CROSSOVER   # `detect`: candidate density above which forward + lp_nms is the faster form
+        self.pass_rate = None      # candidates / anchors of the last batch that went through `detect` (None: not known yet)
+        self._pass_probe = None    # (pinned int32 [B], event, N): asynchronous read-back of the candidate counts
+        self.det_routes = {'det': 0, 'pred': 0}   # how often `detect` took each form (introspection / tests)
         self.input_id = self.tensor(3, 0)
         abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
 
@@ -358,6 +364,13 @@ class Engine:
         self.graph = bool(enable)
         abi.check(self.lib.lp_engine_set_graph(self.h, 1 if enable else 0), 'lp_engine_set_graph')
 
+    def set_single_lane(self, enable=True):
+        """Issue every kernel of a forward on the caller's stream (no side lanes): what several forwards in flight on several
+        streams want (lp_engine_set_single_lane); one forward at a time is 2-3 % faster with the lanes."""
+        if bool(enable) != self.single_lane:
+            self.single_lane = bool(enable)
+            abi.check(self.lib.lp_engine_set_single_lane(self.h, 1 if enable else 0), 'lp_engine_set_single_lane')
+
     def copy_tuning(self, other):
         """Take over the tuned kernel variants (all shapes) of ``other``, an engine of the same model and dtype."""
         abi.check(self.lib.lp_engine_copy_tuning(self.h, other.h), 'lp_engine_copy_tuning')
@@ -381,13 +394,25 @@ class Engine:
         return flat.view(B, h.value, w.value, cs.value)[..., :c.value].permute(0, 3, 1, 2)
 
     def prepare(self, B, H, W, x_dtype=None):
-        """Bind the shape and run the one-off kernel-variant tuner for it on a dummy batch, so that callers who time their
-        forwards (Evaler / Inferer speed protocol) do not fold tuning or graph capture into the first timed batch."""
-        if (B, H, W) == self.bound and (not self.autotune or self.bound in self.tuned):
+        """Run the one-off kernel-variant tuner for a new shape on a dummy batch, so that callers who time their forwards
+        (Evaler / Inferer speed protocol) do not fold the tuner (hundreds of timed launches) into the first timed batch.
+        Does nothing for a shape that is already tuned, or that will never be (tuner off, or ``max_tuned_shapes`` reached):
+        ``forward`` re-binds such a shape by itself, which is cheap.  No hipGraph is captured here: graphs are keyed on the
+        input pointer (lp_engine_forward), so one captured for the dummy tensor could never be replayed; the caller's first
+        forward captures its own."""
+        shape = (B, H, W)
+        if not self.autotune or shape in self.tuned or len(self.tuned) >= self.max_tuned_shapes:
             return
         x = torch.zeros(B, 3, H, W, dtype=x_dtype or self.dtype, device=self.device)
-        self.forward(x)
-        torch.cuda.current_stream(self.device).synchronize()
+        graph = self.graph
+        if graph:
+            self.set_graph(False)
+        try:
+            self.forward(x)
+            torch.cuda.current_stream(self.device).synchronize()
+        finally:
+            if graph:
+                self.set_graph(True)
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
@@ -402,12 +427,7 @@ class Engine:
                 if self._graph_pred is None or self._graph_pred.shape != (B, self.n_anchors, abi.LP_PRED_COLS):
                     self._graph_pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
                 pred = self._graph_pred
-                gx = getattr(self, '_graph_x', None)
-                if gx is None or gx.shape != x.shape or gx.dtype != x.dtype:
-                    gx = self._graph_x = torch.empty_like(x)
-                if gx.data_ptr() != x.data_ptr():
-                    gx.copy_(x)         # a frame-sized copy on the caller's stream; the graph reads the staging buffer
-                x = gx
+                x = self._stage_for_graph(x)
             else:
                 pred = torch.empty(B, self.n_anchors, abi.LP_PRED_COLS, dtype=torch.float32, device=self.device)
             if self.autotune and self.bound not in self.tuned and len(self.tuned) < self.max_tuned_shapes:
@@ -419,6 +439,15 @@ class Engine:
             abi.check(self.lib.lp_engine_forward(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
                                                  ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
         return pred
+
+    def _stage_for_graph(self, x):
+        """Graph mode: the captured graph reads a persistent staging buffer (a frame-sized copy on the caller's stream)."""
+        gx = self._graph_x
+        if gx is None or gx.shape != x.shape or gx.dtype != x.dtype:
+            gx = self._graph_x = torch.empty_like(x)
+        if gx.data_ptr() != x.data_ptr():
+            gx.copy_(x)
+        return gx
 
     def forward_det(self, x, conf_thres, ws=None):
         """Detections-only forward (lp_engine_forward_det) on the current stream: the head writes NMS candidates into the
@@ -447,6 +476,8 @@ class Engine:
             elif ws.numel() < need + 256:
                 raise ValueError('workspace too small: %d bytes needed' % (need + 256))
             wsp = ctypes.c_void_p((ws.data_ptr() + 255) // 256 * 256)
+            if self.graph:
+                x = self._stage_for_graph(x)
             abi.check(self.lib.lp_engine_forward_det(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype], float(conf_thres), wsp, need,
                                                      self._stream()), 'lp_engine_forward_det')
         return ws, B, N
@@ -457,10 +488,47 @@ class Engine:
             self.bind(B, H, W)
             return torch.empty(self.lib.lp_nms_workspace_bytes(B, self.n_anchors) + 256, dtype=torch.uint8, device=self.device)
 
-    def detect(self, x, conf_thres, iou_thres, max_det, want_keep=False):
-        """Detections-only forward + NMS (lp_engine_forward_det + lp_nms_candidates): (det[B,max_det,28], count[B] int32, keep or
-        None), bit-identical to ``nms_padded(self.forward(x), ...)`` without the [B,N,290] prediction tensor ever being written."""
-        return nms_candidates(self.forward_det(x, conf_thres), iou_thres, max_det, want_keep)
+    def detect(self, x, conf_thres, iou_thres, max_det, want_keep=False, route=None):
+        """``non_max_suppression(Model.forward(x))`` as one call: (det[B,max_det,28], count[B] int32, keep or None).
+
+        Two forms give the same bits (tested): the detections-only forward (lp_engine_forward_det + lp_nms_candidates: the head
+        writes NMS candidates, the [B,N,290] prediction tensor is never written) and forward + lp_nms through that tensor.  The
+        first wins while few anchors pass the confidence mask (yololps bs=32 at 3.5 %: +5 %; yololpn bs=128 at 17.6 %: +11 %),
+        the second when nearly all do (100 %: the 112-byte candidate rows cost more than the tensor they replace, -9 %;
+        DESIGN 6.3).  ``route`` None picks by the candidate density of the previous batch (``pass_rate``, read back
+        asynchronously: no host sync here) against ``det_crossover``; 'det' / 'pred' force a form."""
+        if route is None:
+            self._poll_pass_rate()
+            route = 'pred' if (self.pass_rate is not None and self.pass_rate > self.det_crossover) else 'det'
+        self.det_routes[route] += 1
+        if route == 'pred':
+            pred = self.forward(x)
+            out = nms_padded(pred, conf_thres, iou_thres, max_det, want_keep)
+            ws = _nms_ws[(self.device, torch.cuda.current_stream(self.device).cuda_stream)]
+            self._probe_pass_rate(ws, pred.shape[0], pred.shape[1])
+            return out
+        handle = self.forward_det(x, conf_thres)
+        out = nms_candidates(handle, iou_thres, max_det, want_keep)
+        self._probe_pass_rate(*handle)
+        return out
+
+    def _probe_pass_rate(self, ws, B, N):
+        """Queue a copy of the workspace's per-image candidate counts to pinned host memory behind the work just enqueued."""
+        with torch.cuda.device(self.device):
+            base = (ws.data_ptr() + 255) // 256 * 256
+            ptr = self.lib.lp_nms_candidate_counts(ctypes.c_void_p(base), B, N)
+            off = ptr - ws.data_ptr()
+            pr = self._pass_probe
+            if pr is None or pr[0].numel() != B:
+                pr = (torch.empty(B, dtype=torch.int32).pin_memory(), torch.cuda.Event(), N)
+            pr[0].copy_(ws[off:off + 4 * B].view(torch.int32), non_blocking=True)
+            pr[1].record(torch.cuda.current_stream(self.device))
+            self._pass_probe = (pr[0], pr[1], N)
+
+    def _poll_pass_rate(self):
+        pr = self._pass_probe
+        if pr is not None and pr[1].query():
+            self.pass_rate = float(pr[0].float().mean()) / max(1, pr[2])
 
     def profile(self, x, reps=3, inner=1):
         """Per-op device milliseconds (hipEvent pairs around ``inner`` back-to-back launches of each op) + op descriptions,
@@ -521,7 +589,7 @@ def engine_for(model, dtype=None):
 
 
 def prepare_for(model, shape, x_dtype=None):
-    """Untimed set-up (bind + autotune + graph capture) of ``model``'s engine for input shape [B,3,H,W]."""
+    """Untimed set-up (the one-off kernel-variant tuner) of ``model``'s engine for input shape [B,3,H,W]."""
     eng = engine_for(model)
     if bool(getattr(model, 'lp_graph', False)) != eng.graph:
         eng.set_graph(getattr(model, 'lp_graph', False))
@@ -559,15 +627,18 @@ def nms_candidates(handle, iou_thres, max_det, want_keep=False):
     return det, count, keep
 
 
-def detect_padded(model, x, conf_thres, iou_thres, max_det, want_keep=False):
-    """``Model.forward`` + ``non_max_suppression`` of a GPU model as one call that never materialises the prediction tensor:
-    (det[B,max_det,28], count[B], keep or None).  For callers that only want detections (Inferer, Evaler.predict, bench.py)."""
-    return engine_for(model).detect(x, conf_thres, iou_thres, max_det, want_keep)
+def detect_padded(model, x, conf_thres, iou_thres, max_det, want_keep=False, route=None):
+    """``Model.forward`` + ``non_max_suppression`` of a GPU model as one call: (det[B,max_det,28], count[B], keep or None);
+    see ``Engine.detect`` for the two forms it chooses between.  For callers that only want detections (Inferer, serving)."""
+    eng = engine_for(model)
+    if bool(getattr(model, 'lp_graph', False)) != eng.graph:
+        eng.set_graph(getattr(model, 'lp_graph', False))
+    return eng.detect(x, conf_thres, iou_thres, max_det, want_keep, route)
 
 
-def detect(model, x, conf_thres, iou_thres, max_det):
+def detect(model, x, conf_thres, iou_thres, max_det, route=None):
     """Reference-shaped result of ``non_max_suppression(model(x)[0], ...)``: list (len B) of [n_i, 28] tensors."""
-    det, count, _ = detect_padded(model, x, conf_thres, iou_thres, max_det)
+    det, count, _ = detect_padded(model, x, conf_thres, iou_thres, max_det, route=route)
     return [det[b, :n] for b, n in enumerate(count.cpu().tolist())]
 
 
