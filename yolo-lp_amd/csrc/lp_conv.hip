@@ -266,13 +266,20 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
 
 // Row-writer form of the class predictors (lp_head_rows.inc): whether the op fits, and the launch.
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c) {
-    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168 + 6 * 32 * 8 * 4 + 32 * 4 + 32 * 8 * 4;
+    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 + 32 * 1168;
     return nchunks >= 1 && nchunks <= 3 && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) && out_c == LP_PRED_COLS - 13;
+}
+// ... and of its detections-only form (head_det_kernel stages six rows at a time: four K-chunks of resident weights fit)
+bool head_det_fits(int dtype, int nchunks, int cb_pack, int out_c) {
+    const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 * 4 + 16 + 6 * 32 * 8 * 4 + 6 * 1168;
+    return nchunks >= 1 && nchunks <= (dtype == LP_F32 ? 3 : 4) && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) &&
+           out_c == LP_PRED_COLS - 13;
 }
 
 int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) {
     const int nchunks = a.chunk_begin[a.nsrc];
-    if (!head_rows_fits(dtype, nchunks, cb_pack, a.out_c)) return fail(LP_ERR_ARG, "head rows: op does not fit");
+    if (!(a.det_mode ? head_det_fits(dtype, nchunks, cb_pack, a.out_c) : head_rows_fits(dtype, nchunks, cb_pack, a.out_c)))
+        return fail(LP_ERR_ARG, "head rows: op does not fit");
     const int kc = 128 / (int)dtype_size(dtype);
     for (int i = 0; i < a.nsrc; ++i)                       // whole K-chunks, or ONE partial chunk of whole 16-channel K-steps
         if (a.src[i].cs % kc != 0 && !(a.src[i].cs < kc && a.src[i].cs % (kc / 4) == 0))

@@ -510,6 +510,7 @@ extern "C" int lp_engine_upload(lp_engine* e, void* dev_weights, void* stream) {
 }
 
 static bool rows_fits(const lp_engine* e, const Op& op);
+static bool det_fits(const lp_engine* e, const Op& op);
 
 // ---- arena ----------------------------------------------------------------------------------------------
 // Tensors back to back; behind them, for the detections-only forward, a prediction scratch [B][h*w][290] fp32 for every
@@ -529,7 +530,7 @@ static size_t place(const lp_engine* e, int B, int H, int W, std::vector<Tensor>
     if (scratch) scratch->assign(e->ops.size(), (size_t)-1);
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& op = e->ops[i];
-        if (op.kind != OP_HEAD_CLS || rows_fits(e, op)) continue;
+        if (op.kind != OP_HEAD_CLS || det_fits(e, op)) continue;
         if (scratch) (*scratch)[i] = off;
         off += ((size_t)B * (H >> (3 + op.level)) * (W >> (3 + op.level)) * LP_PRED_COLS * 4 + 255) / 256 * 256;
     }
@@ -667,6 +668,17 @@ static bool rows_fits(const lp_engine* e, const Op& op) {
         if (cs % kc != 0 && !(cs < kc && cs % (kc / 4) == 0)) return false;
     }
     return head_rows_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
+}
+
+// Whether the detections-only class-predictor kernel (head_det_kernel) can run the op.
+static bool det_fits(const lp_engine* e, const Op& op) {
+    if (op.kind != OP_HEAD_CLS || getenv("LP_NO_HEAD_DET")) return false;
+    const int kc = 128 / (int)dtype_size(e->dtype);
+    for (int i = 0; i < op.nsrc; ++i) {
+        const int cs = e->tensors[op.src[i]].cs;
+        if (cs % kc != 0 && !(cs < kc && cs % (kc / 4) == 0)) return false;
+    }
+    return head_det_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
 }
 
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
