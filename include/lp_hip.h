@@ -74,6 +74,10 @@ typedef struct lp_conv_desc {
     float res_alpha;
     const float* weight;    /* host, fp32, [Cout][Cin_total][k][k]  (torch Conv2d.weight, BN already folded) */
     const float* bias;      /* host, fp32, [Cout] */
+    int dst2;               /* <= 0 (tensor 0 is the network input, never a destination): none; else a second destination: TWO sibling layers of the reference that read the same input with the same
+                             * kernel size, stride and activation (the class and box towers of a head level, effidehead.py:232-244; cv1 /
+                             * cv2 of SimCSPSPPF and BepC3, common.py:139-141,497-500) run as ONE launch: weight / bias hold the rows of the
+                             * first layer (dst's channels, a multiple of 8) followed by those of the second (dst2's).  No residual. */
 } lp_conv_desc;
 
 /* act(conv(cat(src...)) + bias) [+ alpha*res].  Replaces RepVGGBlock deploy forward (common.py:258-259),

@@ -59,7 +59,7 @@ def test_abi_argument_validation():
     assert lib.lp_nms(None, 1, 1, 0.4, 0.45, 10, None, None, None, None, 0, None) < 0
 
 
-@pytest.mark.parametrize('name,n_ops,weight_mb', [('yololps', 73, 37.3), ('yololpn', 73, 9.4), ('yolov6m', 110, 70.0)])
+@pytest.mark.parametrize('name,n_ops,weight_mb', [('yololps', 69, 37.3), ('yololpn', 69, 9.4), ('yolov6m', 99, 70.0)])
 def test_engine_graph_builds_for_baseline_configs(name, n_ops, weight_mb):
     from yolov6.hip.runtime import Engine
     from yolov6.utils.synth import build_synthetic

@@ -40,7 +40,7 @@ H = W = args.hw << sl
 stamps = None
 if args.stamps:
     import ctypes
-    stamps = torch.zeros(1 << 20, dtype=torch.int64, device='cuda:0')
+    stamps = torch.zeros(1 << 20, dtype=torch.int64, device='cuda:0')     # (rows of 8: per-wave totals; from 1 << 19: prologue detail)
     eng.lib.lpdbg_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 eng.bind(args.batch, H, W)
 if args.variant:
@@ -59,6 +59,15 @@ if stamps is not None:
         ghz = (clk[:, 0] / clk[:, 1].clamp(min=1)) * 0.1
         print('in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %d waves; wave lifetime median %.1f us, max %.1f us'
               % (ghz.median(), ghz.min(), ghz.max(), clk.shape[0], clk[:, 1].median() / 100, clk[:, 1].max() / 100))
+        us = lambda col: (clk[:, col] / (ghz * 1e3)).median().item()    # noqa: E731
+        print('per wave (median): prologue %.2f us, epilogues %.2f us, drain of the last stores %.2f us, chunk loop %.2f us'
+              % (us(2), us(3), us(4), ((clk[:, 0] - clk[:, 2] - clk[:, 3] - clk[:, 4]) / (ghz * 1e3)).median().item()))
+        p2 = stamps[1 << 19:].view(-1, 8).cpu().double()
+        p2 = p2[p2[:, 7] == 5]
+        if p2.shape[0]:
+            g = ghz.median().item() * 1e3
+            print('prologue in detail (median us): index math %.2f, tile decode + request of chunks 0, 1 %.2f, bias + chunk tables %.2f, wait for my pieces %.2f, barrier + first reads %.2f'
+                  % tuple((p2[:, k] / g).median().item() for k in range(5)))
         sys.exit(0)
     st = st[st[:, 7] == 1].double()
     n = st.shape[0]

@@ -222,13 +222,22 @@ extern "C" int lp_engine_add_conv(lp_engine* e, const lp_conv_desc* d) {
         if (!valid_tensor(e, d->res) || e->tensors[d->res].c != td.c || e->tensors[d->res].sl != td.sl || d->res == d->dst)
             return fail(LP_ERR_ARG, "lp_engine_add_conv: residual shape");
     }
+    int cout2 = 0;
+    if (d->dst2 > 0) {       // two sibling layers as one launch
+        if (!valid_tensor(e, d->dst2) || d->dst2 == d->dst || e->tensors[d->dst2].sl != td.sl) return fail(LP_ERR_ARG, "lp_engine_add_conv: dst2");
+        for (int i = 0; i < d->n_src; ++i) if (d->src[i] == d->dst2) return fail(LP_ERR_ARG, "lp_engine_add_conv: in-place conv");
+        if (d->res >= 0) return fail(LP_ERR_UNSUPPORTED, "lp_engine_add_conv: no residual with two destinations");
+        if (td.c % 8 != 0) return fail(LP_ERR_UNSUPPORTED, "lp_engine_add_conv: the first destination of two needs a multiple of 8 channels");
+        cout2 = e->tensors[d->dst2].c;
+    }
     op.dst = d->dst;
+    op.dst2 = d->dst2 > 0 ? d->dst2 : -1;
     op.ksize = d->ksize;
     op.stride = d->stride;
     op.act = d->act;
     op.res = d->res >= 0 ? d->res : -1;
     op.alpha = d->res_alpha;
-    op.cout = td.c;
+    op.cout = td.c + cout2;       // (td.c is its stored width when a second destination follows: the rows are contiguous)
     op.cin = cin;
     op.weight.assign(d->weight, d->weight + (size_t)op.cout * cin * d->ksize * d->ksize);
     op.bias.assign(d->bias, d->bias + op.cout);
@@ -423,7 +432,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         }
         else {
             op.mode = MODE_ACT;
-            cout_store = e->tensors[op.dst].cs;
+            cout_store = e->tensors[op.dst].cs + (op.kind == OP_CONV && op.dst2 >= 0 ? e->tensors[op.dst2].cs : 0);
             op.cfg = pick_cfg(dt, ks, st, cout_store);
             // default variant of the 128-cout class; lp_engine_autotune() picks per layer among the variants that
             // share this packing.  LP_TUNE_CFG128 / LP_TUNE_NBUF force one for experiments.
@@ -628,7 +637,7 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
             const Tensor& d = e->tensors[op.dst];
             fl = 2.0 * e->B * d.h * d.w * op.cout * (op.alg_kk ? op.alg_kk : op.cin * op.ksize * op.ksize);
             for (int k = 0; k < op.nsrc; ++k) by += tbytes(op.src[k]);
-            by += tbytes(op.dst) + (op.res >= 0 ? tbytes(op.res) : 0) + (double)op.cout * op.cin * op.ksize * op.ksize * esz;
+            by += tbytes(op.dst) + (op.dst2 >= 0 ? tbytes(op.dst2) : 0) + (op.res >= 0 ? tbytes(op.res) : 0) + (double)op.cout * op.cin * op.ksize * op.ksize * esz;
             break;
         }
         case OP_DECONV: fl = 2.0 * in_px * op.cin * op.cout * 4; by = tbytes(op.src[0]) + tbytes(op.dst) + 4.0 * op.cin * op.cout * esz; break;
@@ -652,7 +661,7 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
 // Whether the streaming 1x1 kernel (wc cout tiles per wave) can run the op: dense 1x1 stride-1 conv whose packing has whole
 // cout tiles of the wave, sources made of whole 128-byte K-chunks, resident weights + staging within the LDS.
 static bool stream_fits(const lp_engine* e, const Op& op, int wc) {
-    if (op.kind != OP_CONV || op.ksize != 1 || op.stride != 1 || op.mode != MODE_ACT) return false;
+    if (op.kind != OP_CONV || op.ksize != 1 || op.stride != 1 || op.mode != MODE_ACT || op.dst2 >= 0) return false;
     const int kc = 128 / (int)dtype_size(e->dtype);
     for (int i = 0; i < op.nsrc; ++i)
         if (e->tensors[op.src[i]].cs % kc != 0) return false;
@@ -726,6 +735,14 @@ static int prepare_op(lp_engine* e, size_t idx) {
         a.out_c = d.cs;
         a.out_pix_stride = d.cs;
         a.out_img_stride = (long long)d.h * d.w * d.cs;
+        if (op.kind == OP_CONV && op.dst2 >= 0) {
+            const Tensor& d2 = e->tensors[op.dst2];
+            a.out2 = tptr(op.dst2);
+            a.out_split = d.cs;
+            a.out_c = d.cs + d2.cs;
+            a.out2_pix_stride = d2.cs;
+            a.out2_img_stride = (long long)d2.h * d2.w * d2.cs;
+        }
         if (op.res >= 0) { a.res = tptr(op.res); a.res_cs = e->tensors[op.res].cs; }
     } else {
         a.out = nullptr;   // patched per call: pred + pred_off
@@ -819,7 +836,7 @@ static bool stem2_fused_possible(const lp_engine* e) {
     if (!stem_planar_possible(e) || e->ops.size() < 3) return false;
     const Op& s = e->ops[1];
     const Op& c = e->ops[2];
-    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.src[0] != s.dst || c.res >= 0 || c.mode != MODE_ACT ||
+    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.src[0] != s.dst || c.res >= 0 || c.dst2 >= 0 || c.mode != MODE_ACT ||
         c.nct != 1 || c.nphase != 1 || c.nchunks < 1 || c.nchunks > 2 || s.act != LP_ACT_RELU || c.act != LP_ACT_RELU) return false;
     const int cb = conv_shape(e->dtype, c.cfg, 3, 2).CB, cs2 = e->tensors[c.dst].cs;
     if ((cb != 32 && cb != 64) || cb != 32 * ((cs2 + 31) / 32) || e->tensors[s.dst].cs > 16 * c.nchunks) return false;
@@ -836,8 +853,8 @@ static bool pw_fused_possible(const lp_engine* e, size_t i) {
     if (e->dtype == LP_F32 || i < 2 || i >= e->ops.size()) return false;
     const Op& p = e->ops[i - 1];
     const Op& c = e->ops[i];
-    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.res >= 0 || c.mode != MODE_ACT || c.nct != 1 || c.nphase != 1) return false;
-    if (p.kind != OP_CONV || p.ksize != 1 || p.stride != 1 || p.nsrc != 1 || p.res >= 0 || p.mode != MODE_ACT || p.nct != 1 || p.nphase != 1 ||
+    if (c.kind != OP_CONV || c.ksize != 3 || c.stride != 2 || c.nsrc != 1 || c.res >= 0 || c.dst2 >= 0 || c.mode != MODE_ACT || c.nct != 1 || c.nphase != 1) return false;
+    if (p.kind != OP_CONV || p.ksize != 1 || p.stride != 1 || p.nsrc != 1 || p.res >= 0 || p.dst2 >= 0 || p.mode != MODE_ACT || p.nct != 1 || p.nphase != 1 ||
         p.nchunks != 1 || p.dst != c.src[0] || p.lane != c.lane || p.signal) return false;
     const int cs0 = e->tensors[p.src[0]].cs, cs1 = e->tensors[p.dst].cs, cs2 = e->tensors[c.dst].cs;
     if (cs0 != 64 || (cs1 != 32 && cs1 != 64) || (cs2 != 32 && cs2 != 64)) return false;

@@ -63,6 +63,10 @@ struct ConvArgs {
     const void* zero;       // 128 zero bytes: DMA source of out-of-image / out-of-range granules
     void* trash;            // 16 writable bytes nobody reads: target of stores that must not happen (streaming 1x1 kernel)
     void* out;
+    void* out2;             // MODE_ACT, two sibling layers as one launch: output channels >= out_split go to this tensor (channel c - out_split,
+    int out_split;          // pixel stride out2_pix_stride, image stride out2_img_stride); null: a single destination
+    int out2_pix_stride;
+    long long out2_img_stride;
     const void* res;        // residual (same dtype/geometry as out) or null
     int res_cs;
     float alpha;

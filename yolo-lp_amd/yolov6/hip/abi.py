@@ -25,7 +25,7 @@ CSRC_DIR = os.path.join(_PKG_ROOT, 'csrc')
 class ConvDesc(ctypes.Structure):
     """lp_conv_desc"""
     _fields_ = [('n_src', c_int), ('src', c_int * LP_MAX_SRC), ('dst', c_int), ('ksize', c_int), ('stride', c_int),
-                ('act', c_int), ('res', c_int), ('res_alpha', c_float), ('weight', c_void_p), ('bias', c_void_p)]
+                ('act', c_int), ('res', c_int), ('res_alpha', c_float), ('weight', c_void_p), ('bias', c_void_p), ('dst2', c_int)]
 
 
 #: name -> (restype, argtypes): every symbol include/lp_hip.h declares

@@ -38,6 +38,8 @@ def _act_of(module):
 
 
 def _f32(t):
+    if isinstance(t, np.ndarray):
+        return np.ascontiguousarray(t, dtype=np.float32)
     return np.ascontiguousarray(t.detach().float().cpu().numpy())
 
 
@@ -81,6 +83,9 @@ class Engine:
         self.max_tuned_shapes = 32   # a directory of oddly sized frames must not pay the tuner for every new shape
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
         self.single_lane = False   # set_single_lane
+        self.fuse_siblings = os.environ.get('LP_NO_SIBLINGS') is None   # sibling layers on one input as one launch (conv_pair)
+        self._last_stream = None   # stream + event of the last forward: a forward on ANOTHER stream waits for it (one arena)
+        self._last_event = None
         self._graph_pred = None
         self._graph_x = None       # graph mode: persistent staging copy of the input (fixed address)
         self.det_crossover = DET_CROSSOVER   # `detect`: candidate density above which forward + lp_nms is the faster form
@@ -152,8 +157,39 @@ class Engine:
         d.res = -1 if res is None else res
         d.res_alpha = float(alpha)
         d.weight, d.bias = self._ptr(w), self._ptr(b)
+        d.dst2 = -1
         abi.check(self.lib.lp_engine_add_conv(self.h, ctypes.byref(d)), 'lp_engine_add_conv')
         return dst
+
+    def conv_pair(self, srcs, wb1, wb2, k, s, act, sl):
+        """Two sibling layers on the same input (same kernel size, stride, activation) as ONE launch with two destination
+        tensors (lp_conv_desc.dst2): their weight rows stacked.  The sums of every output channel are those of the two
+        separate layers (a cout tile never mixes rows), so the results are the same bits.  Returns (dst1, dst2)."""
+        (w1, b1), (w2, b2) = [(_f32(w), _f32(b)) for w, b in (wb1, wb2)]
+        if w1.shape[0] % 8 != 0 or not self.fuse_siblings:
+            return (self.conv(srcs, w1, b1, k, s, act, sl), self.conv(srcs, w2, b2, k, s, act, sl))
+        w, b = np.ascontiguousarray(np.concatenate([w1, w2], 0)), np.ascontiguousarray(np.concatenate([b1, b2], 0))
+        sl_out = sl + (1 if s == 2 else 0)
+        dst1, dst2 = self.tensor(w1.shape[0], sl_out), self.tensor(w2.shape[0], sl_out)
+        d = abi.ConvDesc()
+        d.n_src = len(srcs)
+        for i in range(abi.LP_MAX_SRC):
+            d.src[i] = srcs[i] if i < len(srcs) else -1
+        d.dst, d.ksize, d.stride, d.act = dst1, k, s, act
+        d.res, d.res_alpha = -1, 0.0
+        d.weight, d.bias = self._ptr(w), self._ptr(b)
+        d.dst2 = dst2
+        abi.check(self.lib.lp_engine_add_conv(self.h, ctypes.byref(d)), 'lp_engine_add_conv')
+        return dst1, dst2
+
+    def cba_pair(self, m1, m2, srcs, sl):
+        """Two Conv / SimConv / Conv_C3 modules reading the same input: one launch when their shapes allow it."""
+        c1, c2 = m1.conv, m2.conv
+        same = (c1.kernel_size == c2.kernel_size and c1.stride == c2.stride and _act_of(m1.act) == _act_of(m2.act)
+                and c1.in_channels == c2.in_channels)
+        if not same:
+            return self.cba(m1, srcs, sl), self.cba(m2, srcs, sl)
+        return self.conv_pair(srcs, _folded(m1), _folded(m2), c1.kernel_size[0], c1.stride[0], _act_of(m1.act), sl)
 
     # -- module -> ops ---------------------------------------------------------
     def cba(self, m, srcs, sl):
@@ -202,12 +238,10 @@ class Engine:
 
     def bepc3(self, m, srcs, sl):
         """BepC3 (common.py:479-501): cv3 reads [m(cv1 x), cv2 x] as two sources."""
+        if m.concat is True:                              # cv1 and the shortcut cv2 read the same input: one launch
+            c1, c2 = self.cba_pair(m.cv1, m.cv2, srcs, sl)
+            return self.cba(m.cv3, [self.rep_block(m.m, [c1], sl), c2], sl)
         a = self.rep_block(m.m, [self.cba(m.cv1, srcs, sl)], sl)
-        if m.concat is True:
-            self.lane(1)                                  # the shortcut branch overlaps the BottleRep stage
-            c2 = self.cba(m.cv2, srcs, sl)
-            self.lane(0)
-            return self.cba(m.cv3, [a, c2], sl)
         return self.cba(m.cv3, [a], sl)
 
     def stage(self, m, srcs, sl):
@@ -225,10 +259,8 @@ class Engine:
     def merge_layer(self, m, x, sl):
         """SimCSPSPPF / CSPSPPF (common.py:124-172) or SimSPPF / SPPF (:88-121); concats are multi-source reads."""
         if isinstance(m, L._CSPSPPFBase):
-            self.lane(1)                                  # the CSP shortcut overlaps the trunk
-            y0 = self.cba(m.cv2, [x], sl)
-            self.lane(0)
-            x1 = self.cba(m.cv4, [self.cba(m.cv3, [self.cba(m.cv1, [x], sl)], sl)], sl)
+            c1, y0 = self.cba_pair(m.cv1, m.cv2, [x], sl)         # the trunk's first layer and the CSP shortcut read the same input
+            x1 = self.cba(m.cv4, [self.cba(m.cv3, [c1], sl)], sl)
             y3 = self.cba(m.cv6, [self.cba(m.cv5, [x1] + self.pools(x1, sl, m.cv4.conv.out_channels), sl)], sl)
             return self.cba(m.cv7, [y0, y3], sl)
         if isinstance(m, L._SPPFBase):
@@ -320,14 +352,13 @@ class Engine:
         sl = 3 + i
         self.lane(lanes[0])
         s = self.cba(det.stems[i], [f], sl)
-        c = self.cba(det.cls_convs[i], [s], sl)
+        c, r = self.cba_pair(det.cls_convs[i], det.reg_convs[i], [s], sl)      # the two towers read the stem's output: one launch
         preds = [getattr(det, '%s_preds' % h)[i] for h in CLS_HEADS]
         wc = np.concatenate([_f32(p.weight).reshape(p.out_channels, -1) for p in preds], 0)
         bc = np.concatenate([_f32(p.bias) for p in preds], 0)
         abi.check(self.lib.lp_engine_add_head_cls(self.h, c, i, wc.shape[0], self._ptr(wc), self._ptr(bc)),
                   'lp_engine_add_head_cls')
         self.lane(lanes[1])
-        r = self.cba(det.reg_convs[i], [s], sl)
         rp, cp = det.reg_preds[i], det.cor_preds[i]
         bins = det.reg_max + 1 if det.use_dfl else 1
         if rp.out_channels != 4 * bins:
@@ -363,6 +394,20 @@ class Engine:
         tensor returned by ``forward`` is then a persistent buffer that the next forward overwrites."""
         self.graph = bool(enable)
         abi.check(self.lib.lp_engine_set_graph(self.h, 1 if enable else 0), 'lp_engine_set_graph')
+
+    def _stream_enter(self):
+        """The engine has ONE activation arena: a forward issued on another stream than the previous one (the model's
+        one-at-a-time callers and an InflightForward slot share engine 0) first waits for that one to finish."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._last_event is not None and self._last_stream != cur.cuda_stream:
+            cur.wait_event(self._last_event)
+        return cur
+
+    def _stream_leave(self, cur):
+        if self._last_event is None:
+            self._last_event = torch.cuda.Event()
+        self._last_event.record(cur)
+        self._last_stream = cur.cuda_stream
 
     def set_single_lane(self, enable=True):
         """Issue every kernel of a forward on the caller's stream (no side lanes): what several forwards in flight on several
@@ -422,6 +467,7 @@ class Engine:
         x = x.contiguous()
         B, _, H, W = x.shape
         with torch.cuda.device(self.device):
+            cur = self._stream_enter()
             self.bind(B, H, W)
             if self.graph:      # fixed input and output addresses: one captured graph per shape, never re-captured
                 if self._graph_pred is None or self._graph_pred.shape != (B, self.n_anchors, abi.LP_PRED_COLS):
@@ -438,6 +484,7 @@ class Engine:
                 self.tuned.add(self.bound)
             abi.check(self.lib.lp_engine_forward(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype],
                                                  ctypes.c_void_p(pred.data_ptr()), self._stream()), 'lp_engine_forward')
+            self._stream_leave(cur)
         return pred
 
     def _stage_for_graph(self, x):
@@ -465,6 +512,7 @@ class Engine:
         with torch.cuda.device(self.device):
             if self.autotune and (B, H, W) not in self.tuned and len(self.tuned) < self.max_tuned_shapes:
                 self.forward(x)                                 # first batch of this shape: bind + tune through the plain forward
+            cur = self._stream_enter()
             self.bind(B, H, W)
             N = self.n_anchors
             need = self.lib.lp_nms_workspace_bytes(B, N)
@@ -480,6 +528,7 @@ class Engine:
                 x = self._stage_for_graph(x)
             abi.check(self.lib.lp_engine_forward_det(self.h, ctypes.c_void_p(x.data_ptr()), _DT[x.dtype], float(conf_thres), wsp, need,
                                                      self._stream()), 'lp_engine_forward_det')
+            self._stream_leave(cur)
         return ws, B, N
 
     def det_workspace(self, B, H, W):
