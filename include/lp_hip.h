@@ -178,6 +178,8 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
        /* pipelined 3x3 stride-1 kernel (persistent, 3-slot LDS ring, nbuf 3): 128 couts x 256 px, 64 x 512, 128 x 128, 32 x 512 */
        LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35,
        LP_VARIANT_PIPE_P = 36 /* 32 x 512, the stem reading the NCHW frame (see above) */,
+       LP_VARIANT_PIPE_DL = 39, LP_VARIANT_PIPE_BL = 40, LP_VARIANT_PIPE_FL = 41 /* PIPE_D / B / F with four loader waves per workgroup that do
+                                       * the LDS-DMA of the ring in place of the eight multiplying waves (nbuf 3) */,
        LP_VARIANT_FUSED_STEM2 = 37 /* op 2 only (3x3 stride 2 behind the stem, <= 64 channels): input op + stem + this layer as ONE kernel
                                       whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */,
        LP_VARIANT_FUSED_PW_S2 = 38 /* a 3x3 stride-2 layer (<= 64 channels) whose input comes from a 1x1 layer (64 -> <= 64 channels) that nobody

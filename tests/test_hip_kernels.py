@@ -433,7 +433,7 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     base, tried = None, 0
-    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3)]:   # 32..35: LP_VARIANT_PIPE_*
+    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3), (39, 3), (40, 3), (41, 3)]:   # 32..35: LP_VARIANT_PIPE_*, 39..41: with loader waves
         try:
             eng.set_variant(op, cfg, nb)
         except RuntimeError:
@@ -503,7 +503,7 @@ def test_conv3x3_pipe(case, dtype):
         ref = q(ref) + 0.75 * q(res)
     assert rel_err(base.float().cpu(), ref) <= TOL[dtype]
     tried = 0
-    for cfg in (32, 33, 34, 35):
+    for cfg in (32, 33, 34, 35, 39, 40, 41):          # pipelined variants, without and with loader waves
         try:
             eng.set_variant(op, cfg, 3)
         except RuntimeError:

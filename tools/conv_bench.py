@@ -68,6 +68,12 @@ if stamps is not None:
             g = ghz.median().item() * 1e3
             print('prologue in detail (median us): index math %.2f, tile decode + request of chunks 0, 1 %.2f, bias + chunk tables %.2f, wait for my pieces %.2f, barrier + first reads %.2f'
                   % tuple((p2[:, k] / g).median().item() for k in range(5)))
+        p3 = stamps[(1 << 19) + (1 << 18):].view(-1, 8).cpu().double()
+        p3 = p3[p3[:, 7] == 6]
+        if p3.shape[0]:
+            tot = p3[:, :4].sum(1)
+            print('chunk loop (stamped once per chunk: perturbs the read pipeline), share of the clocks: MFMA steps + reads %.1f %%, wait for my DMA pieces %.1f %%, barrier %.1f %%, issue of the next pieces %.1f %%'
+                  % tuple((100 * p3[:, k] / tot).median().item() for k in range(4)))
         sys.exit(0)
     st = st[st[:, 7] == 1].double()
     n = st.shape[0]

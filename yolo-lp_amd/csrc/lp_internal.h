@@ -46,7 +46,12 @@ enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C =
 // Pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc): workgroup configurations
 enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
                  PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
-                 PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/ };
+                 PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/,
+                 PIPE_DL = 7, PIPE_BL = 8, PIPE_FL = 9 /*D / B / F with loader waves: lp_conv3x3_pipel.inc*/, PIPE_END = 10 };
+inline bool pipe_is_loader(int pcfg) { return pcfg >= PIPE_DL && pcfg <= PIPE_FL; }
+#ifndef LP_PIPEL_NL
+#define LP_PIPEL_NL 4             // loader waves per workgroup of conv3x3_pipel_kernel (2: 5-8 % slower than the plain kernel, 4: equal, 8: 1.5x slower)
+#endif
 
 struct ConvSrc {
     const void* ptr;

@@ -14,6 +14,7 @@ LP_VARIANT_STREAM64, LP_VARIANT_STREAM128, LP_VARIANT_ROWS = 16, 17, 18   # lp_e
 LP_VARIANT_PIPE_D, LP_VARIANT_PIPE_B, LP_VARIANT_PIPE_F, LP_VARIANT_PIPE_C = 32, 33, 34, 35        # pipelined 3x3 stride-1 kernel (nbuf 3)
 LP_VARIANT_FUSED_PW_S2 = 38                                                                      # a 1x1 layer + the 3x3 stride-2 layer behind it as one kernel
 LP_VARIANT_FUSED_STEM2 = 37                                                                      # input op + stem + the layer behind it as one kernel
+LP_VARIANT_PIPE_DL, LP_VARIANT_PIPE_BL, LP_VARIANT_PIPE_FL = 39, 40, 41                                  # the same with loader waves (lp_conv3x3_pipel.inc)
 LP_VARIANT_PIPE_P = 36                                                                           # the stem reading the NCHW frame itself
 LP_EVAL_NCOUNTS = 43   # lp_eval_counts: length of the counts vector (include/lp_hip.h)
 

@@ -602,7 +602,7 @@ class Engine:
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
-                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
+                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 39: 'Ld', 40: 'Lb', 41: 'Lf'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
         return ops
 
 
