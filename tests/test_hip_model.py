@@ -457,7 +457,8 @@ def test_nms_on_engine_output_matches_oracle():
     ('yololpn', dict(sigma=0.6), 5, 640, 416, torch.float16),
     ('yolov6m', dict(width=0.125, sigma=1.5), 2, 160, 128, torch.bfloat16),      # DFL head
     ('yololps', dict(width=0.125, sigma=1.5), 2, 256, 256, torch.float32),
-], ids=['lps-tiny', 'lps-full', 'lpn-full', 'v6m-dfl', 'lps-f32'])
+    ('yolov6m', dict(sigma=0.25), 2, 192, 160, torch.bfloat16),                  # 96 / 192-channel towers: a partial last K-chunk in the row kernels
+], ids=['lps-tiny', 'lps-full', 'lpn-full', 'v6m-dfl', 'lps-f32', 'v6m-full'])
 def test_detections_only_forward_matches_forward_plus_nms(name, kw, B, H, W, dtype):
     """lp_engine_forward_det + lp_nms_candidates (the head writes NMS candidates, never the prediction tensor) == lp_nms on the
     prediction tensor of lp_engine_forward: detections, counts and kept anchor indices bit for bit, for the inference and

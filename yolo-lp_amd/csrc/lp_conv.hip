@@ -282,8 +282,8 @@ int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) 
         return fail(LP_ERR_ARG, "head rows: op does not fit");
     const int kc = 128 / (int)dtype_size(dtype);
     for (int i = 0; i < a.nsrc; ++i)                       // whole K-chunks, or ONE partial chunk of whole 16-channel K-steps
-        if (a.src[i].cs % kc != 0 && !(a.src[i].cs < kc && a.src[i].cs % (kc / 4) == 0))
-            return fail(LP_ERR_ARG, "head rows: source channels are neither whole 128-byte chunks nor one partial chunk of 32-byte steps");
+        if (a.src[i].cs % (kc / 4) != 0)
+            return fail(LP_ERR_ARG, "head rows: source channels are not whole 32-byte K-steps");
     if (a.nphase != 1 || a.out_scale != 1 || a.Ho != a.H || a.Wo != a.W || !a.out) return fail(LP_ERR_ARG, "head rows: bad geometry");
     switch (dtype) {
         case LP_F16: return head_rows_launch_f16(a, cb_pack, st);

@@ -674,7 +674,7 @@ static bool rows_fits(const lp_engine* e, const Op& op) {
     const int kc = 128 / (int)dtype_size(e->dtype);
     for (int i = 0; i < op.nsrc; ++i) {                     // whole K-chunks, or one partial chunk of whole 16-channel K-steps (32-channel towers)
         const int cs = e->tensors[op.src[i]].cs;
-        if (cs % kc != 0 && !(cs < kc && cs % (kc / 4) == 0)) return false;
+        if (cs % (kc / 4) != 0) return false;                   // whole 16-channel K-steps (a last K-chunk may be partial: 96, 192 channels)
     }
     return head_rows_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
 }
@@ -685,7 +685,7 @@ static bool det_fits(const lp_engine* e, const Op& op) {
     const int kc = 128 / (int)dtype_size(e->dtype);
     for (int i = 0; i < op.nsrc; ++i) {
         const int cs = e->tensors[op.src[i]].cs;
-        if (cs % kc != 0 && !(cs < kc && cs % (kc / 4) == 0)) return false;
+        if (cs % (kc / 4) != 0) return false;                   // whole 16-channel K-steps (a last K-chunk may be partial: 96, 192 channels)
     }
     return head_det_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
 }
