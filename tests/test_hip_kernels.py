@@ -94,7 +94,8 @@ STREAM_CASES = [
     ([256], 128, 'relu', False, 20, 20, 2),               # 128-row weight packing, four chunks
     ([64, 64, 64, 64], 64, 'relu', False, 12, 20, 2),     # SPPF cv5: four sources
     ([128, 64, 64], 64, 'silu', False, 16, 16, 1),        # BiFusion concat
-    ([96], 192, 'relu', True, 13, 7, 3),                  # 96 channels: whole chunks only in fp32; residual, ragged pixel count
+    ([96], 192, 'relu', True, 13, 7, 3),                  # 96 channels: a partial second K-chunk in f16 / bf16; residual, ragged pixel count
+    ([64, 96, 32], 64, 'relu', False, 11, 9, 2),          # partial chunks in the middle and at the end of a concat
     ([64], 128, 'relu', True, 13, 7, 3),                  # residual with 128 couts per wave
     ([128], 128, 'none', False, 9, 5, 1),                 # fewer pixels than one workgroup's tiles
 ]
@@ -132,7 +133,8 @@ def test_conv1x1_stream(case, variant, dtype):
     base = eng.tensor_view(dst).clone()
     eng.tensor_view(dst).zero_()
     # the kernel takes an op only if its weight packing has whole cout tiles of the wave (the engine packs by least
-    # padding: 128-row tiles only for multiples of 128), every source is made of whole 128-byte K-chunks, and the
+    # padding: 128-row tiles only for multiples of 128), every source is made of whole 32-byte K-steps (a last K-chunk may
+    # be partial: 96 channels), and the
     # resident weights + bias + staging fit the 160 KiB of LDS
     sz = torch.empty(0, dtype=dtype).element_size()
     wc = 2 if variant[0] == 16 else 4
@@ -140,7 +142,7 @@ def test_conv1x1_stream(case, variant, dtype):
     stored = [(c + 7) // 8 * 8 for c in cins]
     nchunks = sum(-(-c // kc) for c in stored)
     lds = nchunks * 32 * wc * 128 + 32 * wc * 4 + 4 * (128 // wc) * (32 * wc * sz + 16)
-    fits = (wc == 2 or cout % 128 == 0) and all(c % kc == 0 for c in stored) and lds <= 160 * 1024 and nchunks <= 8
+    fits = (wc == 2 or cout % 128 == 0) and all(c % (kc // 4) == 0 for c in stored) and lds <= 160 * 1024 and nchunks <= 8
     if not fits:
         with pytest.raises(RuntimeError):
             eng.set_variant(conv_op, *variant)
@@ -588,3 +590,58 @@ def test_iou_predicate_product_form_equals_the_division(iou_thres):
     assert np.array_equal((got & 1) != 0, want)              # the product form == the same
     if 0.0 < iou_thres < 1.0:
         assert want.any() and not want.all()
+
+
+PAIR_CASES = [
+    # (cin list, cout1, cout2, k, act, h, w, B): two sibling layers on one input as ONE launch with two destinations
+    ([64], 64, 64, 1, 'relu', 40, 24, 2),
+    ([96], 64, 64, 1, 'relu', 17, 9, 3),                  # BepC3 cv1 / cv2 of yolov6m: a partial last K-chunk too
+    ([128, 64], 128, 128, 1, 'relu', 20, 20, 2),
+    ([512], 256, 256, 1, 'relu', 20, 20, 2),              # SimCSPSPPF cv1 / cv2
+    ([64], 64, 64, 3, 'silu', 40, 40, 2),                 # the class / box towers of a head level
+    ([128], 128, 128, 3, 'silu', 20, 20, 3),
+    ([16], 8, 24, 3, 'relu', 12, 20, 2),                  # narrow tensors: 8 + 24 channels in one 32-row cout tile
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16, torch.float32], ids=['f16', 'bf16', 'f32'])
+@pytest.mark.parametrize('case', PAIR_CASES, ids=lambda c: '%s-%d+%d-k%d' % ('+'.join(map(str, c[0])), c[1], c[2], c[3]))
+def test_two_destination_conv_equals_two_convs(case, dtype):
+    """lp_conv_desc.dst2 (runtime.Engine.conv_pair): the rows of two sibling layers stacked in one launch give, in each of the two
+    destination tensors, the bits the layer gives alone -- in the default variant and in every variant that takes the op."""
+    from yolov6.hip import abi
+    cins, c1, c2, k, act, h, w, B = case
+    sl = 5
+    eng = _engine(dtype)
+    eng.autotune = False
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    w1, b1 = _rand((c1, cin, k, k), 1, (2.0 / (cin * k * k)) ** 0.5), _rand((c1,), 2, 0.5)
+    w2, b2 = _rand((c2, cin, k, k), 3, (2.0 / (cin * k * k)) ** 0.5), _rand((c2,), 4, 0.5)
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    ra = eng.conv(srcs, w1, b1, k, 1, act_id, sl)
+    rb = eng.conv(srcs, w2, b2, k, 1, act_id, sl)
+    pa, pb = eng.conv_pair(srcs, (w1, b1), (w2, b2), k, 1, act_id, sl)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    for i, (t, c) in enumerate(zip(srcs, cins)):
+        _fill(eng, t, _rand((B, c, h, w), 10 + i))
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    assert op == 3                                        # input + two single convs + ONE pair op
+    _run(eng, B, H, W)
+    want_a, want_b = eng.tensor_view(ra).clone(), eng.tensor_view(rb).clone()
+    assert torch.equal(eng.tensor_view(pa), want_a) and torch.equal(eng.tensor_view(pb), want_b)
+    tried = 0
+    variants = [(c, n) for c in range(6) for n in (1, 2)] + ([(16, 2), (17, 2)] if k == 1 else [(32, 3), (33, 3), (34, 3), (35, 3), (39, 3), (40, 3), (41, 3)])
+    for cfg, nb in variants:
+        try:
+            eng.set_variant(op, cfg, nb)
+        except RuntimeError:
+            continue
+        tried += 1
+        eng.tensor_view(pa).fill_(float('nan'))
+        eng.tensor_view(pb).fill_(float('nan'))
+        _run(eng, B, H, W)
+        assert torch.equal(eng.tensor_view(pa), want_a) and torch.equal(eng.tensor_view(pb), want_b), (cfg, nb)
+    assert tried >= 1

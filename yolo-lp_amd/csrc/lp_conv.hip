@@ -151,9 +151,11 @@ int conv_stream_launch(int dtype, int wc, const ConvArgs& a0, int cb_pack, hipSt
     if (a0.nsrc < 1 || a0.nsrc > LP_MAX_SRC || a0.nphase != 1 || a0.out_scale != 1 || a0.Ho != a0.H || a0.Wo != a0.W ||
         a0.out_img_stride != (long long)a0.Ho * a0.Wo * a0.out_pix_stride)
         return fail(LP_ERR_ARG, "conv1x1 stream: not a dense 1x1 stride-1 layer");
+    if (a0.out2 && (a0.out_split % (32 * wc) != 0 || a0.res || a0.out2_img_stride != (long long)a0.Ho * a0.Wo * a0.out2_pix_stride))
+        return fail(LP_ERR_ARG, "conv1x1 stream: the second destination must start at a cout tile of the wave");
     const int kc = 128 / (int)dtype_size(dtype);
     for (int i = 0; i < a0.nsrc; ++i)
-        if (a0.src[i].cs % kc != 0) return fail(LP_ERR_ARG, "conv1x1 stream: source channels are not whole 128-byte chunks");
+        if (a0.src[i].cs % (kc / 4) != 0) return fail(LP_ERR_ARG, "conv1x1 stream: source channels are not whole 32-byte K-steps");
     ConvArgs a = a0;
     a.nct = ceil_div(a.out_c, 32 * wc);
     switch (dtype) {

@@ -659,12 +659,13 @@ extern "C" int lp_engine_op_info(const lp_engine* e, int i, int* kind, int* ksiz
 
 // ---- execution ------------------------------------------------------------------------------------------
 // Whether the streaming 1x1 kernel (wc cout tiles per wave) can run the op: dense 1x1 stride-1 conv whose packing has whole
-// cout tiles of the wave, sources made of whole 128-byte K-chunks, resident weights + staging within the LDS.
+// cout tiles of the wave, sources made of whole 32-byte K-steps, resident weights + staging within the LDS.
 static bool stream_fits(const lp_engine* e, const Op& op, int wc) {
-    if (op.kind != OP_CONV || op.ksize != 1 || op.stride != 1 || op.mode != MODE_ACT || op.dst2 >= 0) return false;
+    if (op.kind != OP_CONV || op.ksize != 1 || op.stride != 1 || op.mode != MODE_ACT) return false;
+    if (op.dst2 >= 0 && e->tensors[op.dst].cs % (32 * wc) != 0) return false;      // two destinations: the second starts at a cout tile of the wave
     const int kc = 128 / (int)dtype_size(e->dtype);
     for (int i = 0; i < op.nsrc; ++i)
-        if (e->tensors[op.src[i]].cs % kc != 0) return false;
+        if (e->tensors[op.src[i]].cs % (kc / 4) != 0) return false;      // whole 32-byte K-steps (a last K-chunk may be partial)
     return conv_stream_lds(e->dtype, wc, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB) >= 0;
 }
 
