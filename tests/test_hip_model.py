@@ -630,14 +630,17 @@ def test_graph_mode_with_alternating_buffers():
     assert torch.equal(last, ref[11 % 2])
 
 
-@pytest.mark.parametrize('dtype,shape', [(torch.float16, (3, 3, 160, 224)), (torch.bfloat16, (2, 3, 96, 128)), (torch.float16, (1, 3, 640, 640))])
-def test_stem_reading_the_frame_itself_gives_the_same_bits(dtype, shape):
+@pytest.mark.parametrize('dtype,shape,name,width', [(torch.float16, (3, 3, 160, 224), 'yololps', 0.5), (torch.bfloat16, (2, 3, 96, 128), 'yololps', 0.5),
+                                                   (torch.float16, (1, 3, 640, 640), 'yololps', 0.5),
+                                                   (torch.bfloat16, (2, 3, 160, 224), 'yolov6m', 0.75), (torch.float16, (1, 3, 320, 192), 'yolov6m', 0.625)],
+                         ids=['lps-f16', 'lps-bf16', 'lps-640', 'v6m-48ch', 'v6m-40ch'])
+def test_stem_reading_the_frame_itself_gives_the_same_bits(dtype, shape, name, width):
     """LP_VARIANT_PIPE_P: the stem gathers its pixels from the caller's NCHW frame (no input op, no space-to-depth tensor in
     between).  Same prediction bits as the input op + the stem's other kernels; a frame of another dtype takes that route."""
     import ctypes
     from yolov6.hip import runtime, abi
     from yolov6.utils.synth import build_synthetic
-    m = build_synthetic(CFG('yololps'), width=0.5, sigma=1.0).cuda().to(dtype)
+    m = build_synthetic(CFG(name), width=width, sigma=1.0).cuda().to(dtype)      # (yolov6m: a 48- / 40-channel stem: the 64-row form of the kernel)
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(91)).cuda().to(dtype)
     with torch.no_grad():
         eng = runtime.engine_for(m)
@@ -649,7 +652,7 @@ def test_stem_reading_the_frame_itself_gives_the_same_bits(dtype, shape):
         assert cfg.value == abi.LP_VARIANT_PIPE_P
         assert torch.equal(eng.forward(x), base)
         assert torch.equal(eng.forward(x.float()), base)            # fp32 frame: input op + the stem's other kernel
-        eng.set_variant(1, abi.LP_VARIANT_PIPE_C, 3)                # (also switches the planar form off again)
+        eng.set_variant(1, abi.LP_VARIANT_PIPE_C if name == 'yololps' else abi.LP_VARIANT_PIPE_B, 3)      # (also switches the planar form off again; the variant of the stem's packing: 32 / 64 rows)
         assert torch.equal(eng.forward(x), base)
         with pytest.raises(RuntimeError):
             eng.set_variant(2, abi.LP_VARIANT_PIPE_P, 3)            # only the stem has it

@@ -826,7 +826,8 @@ static int prepare_op(lp_engine* e, size_t idx) {
 static bool stem_planar_possible(const lp_engine* e) {
     return e->dtype != LP_F32 && e->ops.size() > 1 && e->ops[0].kind == OP_INPUT && e->ops[0].s2d && e->ops[1].kind == OP_CONV &&
            e->ops[1].ksize == 3 && e->ops[1].stride == 1 && e->ops[1].mode == MODE_ACT && e->ops[1].nct == 1 && e->ops[1].nchunks == 1 &&
-           conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 32 && e->ops[1].res < 0;
+           (conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 32 || conv_shape(e->dtype, e->ops[1].cfg, 3, 1).CB == 64) && e->ops[1].res < 0 &&
+           e->ops[1].dst2 < 0;
 }
 // (the frame must have the engine's dtype and be 16-byte aligned -- the kernels copy it in 16-byte pieces; anything else takes the input op)
 static bool frame_direct(const lp_engine* e, const void* x, int x_dtype) { return x_dtype == e->dtype && ((uintptr_t)x & 15) == 0; }
