@@ -22,30 +22,34 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov6.hip.srchash import source_hash   # noqa: E402
 
 
-def last_values(d, counter, n):
+CONV3 = re.compile(r'conv3x3_\w*kernel|stem_planar_kernel|stem2_fused_kernel|pw_s2_fused_kernel|conv_mfma_kernelI\w+?Li\dELi3E')
+
+
+def step_values(d, counter, steps):
+    """Counter values of the 3x3 dispatches of the last `steps` steps (a step ends with its sort_kernel dispatch) and their number per step."""
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
-    vals = []
-    for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        if r['Counter_Name'] == counter and (re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', k) or 'conv3x3_pipe_kernel' in k or 'stem_planar_kernel' in k or 'stem2_fused_kernel' in k or 'pw_s2_fused_kernel' in k):
-            vals.append(float(r['Counter_Value']))
-    return vals[-n:]
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    ends = [i for i, r in enumerate(rows) if 'sort_kernel' in r['Kernel_Name']]
+    per_step = sum(1 for r in rows[ends[-2] + 1:ends[-1]] if CONV3.search(r['Kernel_Name']))
+    vals = [float(r['Counter_Value']) for r in rows[:ends[-1]] if CONV3.search(r['Kernel_Name'])]
+    return vals[-per_step * steps:], per_step
 
 
 ap = argparse.ArgumentParser()
 ap.add_argument('fetch_dir')
 ap.add_argument('write_dir')
 ap.add_argument('--steps', type=int, default=3)
-ap.add_argument('--launches', type=int, default=47, help='3x3 kernel dispatches per step')
-ap.add_argument('--layers', type=int, default=47, help='3x3 layers per step (the fused stem kernel runs two of them): the per-launch figures are per LAYER, like bench.py roofline')
+ap.add_argument('--bench', required=True, help='a JSON line of bench.py on this build: the number of 3x3 layers per step (the per-launch '
+                'figures are per LAYER, like bench.py roofline; a fused kernel runs two)')
 a = ap.parse_args()
-n = a.steps * a.launches
-fetch = last_values(a.fetch_dir, 'FETCH_SIZE', n)
-write = last_values(a.write_dir, 'WRITE_SIZE', n)
-fetch_b = sum(fetch) / (a.steps * a.layers) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
-write_b = sum(write) / (a.steps * a.layers) * 1024
+layers = json.loads([l for l in open(a.bench).read().splitlines() if l.startswith('{')][-1])['roofline']['launches']
+fetch, per_step = step_values(a.fetch_dir, 'FETCH_SIZE', a.steps)
+write, _ = step_values(a.write_dir, 'WRITE_SIZE', a.steps)
+fetch_b = sum(fetch) / (a.steps * layers) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
+write_b = sum(write) / (a.steps * layers) * 1024
 print(json.dumps({'kernel': '3x3 conv layers (conv3x3_pipe_kernel + stem2_fused_kernel / stem_planar_kernel + conv_mfma_kernel<KS=3>), bytes per LAYER', 'kernel_source_hash': source_hash(),
-                  'dispatches_averaged': len(fetch),
+                  'dispatches_averaged': len(fetch), 'dispatches_per_step': per_step, 'layers_per_step': layers,
                   'fetch_bytes_per_launch': round(fetch_b), 'write_bytes_per_launch': round(write_b),
                   'hbm_bytes_per_launch': round(fetch_b + write_b),
                   'correction': 'FETCH_SIZE KiB x1024 x2 (gfx950 wide reads), WRITE_SIZE KiB x1024'}))

@@ -4,10 +4,9 @@ algorithmic FLOPs of the 3x3 convolution layers of a step / the summed kernel-tr
 TIMED steps (the last steps x launches_per_step matching dispatches; everything before belongs to warm-up and the tuner).
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt1 -- python3 bench.py --steps 50 --warmup 5 --inflight 1 --no-cpu-baseline > bench.json
-    python tools/roofline_from_trace.py gpurun_out/kt1 bench.json --steps 100 > profiles/r03_roofline.json
+    python tools/roofline_from_trace.py gpurun_out/kt1 bench.json --steps 50 > profiles/r03_roofline.json
 
-(one batch in flight: kernels of different batches do not overlap, so a dispatch's duration is its own; bench.py times its
-K steps twice -- with --inflight 1 both passes are one-in-flight -- hence 2 x K steps in the trace).  The file records the hash of
+(one batch in flight, one execution lane: kernels do not overlap, so a dispatch's duration is its own).  The file records the hash of
 the kernel sources; bench.py reports the figure as roofline.frac only when that hash is the running build's.
 """
 import argparse
@@ -38,21 +37,21 @@ def main():
     for f in glob.glob(a.trace_dir + '/**/*kernel_trace.csv', recursive=True):
         rows += [(int(x['Start_Timestamp']), int(x['End_Timestamp']), x['Kernel_Name']) for x in csv.DictReader(open(f))]
     rows.sort()
-    conv = [(e - s) / 1e3 for s, e, n in rows if CONV3.search(n)]
-    # dispatches per step: the fused kernels run two layers each; count from the tail of the trace, which is steady state
-    names = [n for s, e, n in rows if CONV3.search(n)]
-    per_step = r['launches'] - sum(1 for n in names[-r['launches']:] if 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n)
-    # (a window of `launches` dispatches holds at least one step; fused dispatches in it, scaled to one step)
-    fused_per_step = round(sum(1 for n in names[-per_step * a.steps:] if 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n) / a.steps)
-    per_step = r['launches'] - fused_per_step
-    tail = conv[-per_step * a.steps:]
+    # the timed steps: bench.py ends with five forward + lp_nms timings (five greedy_kernel dispatches) behind the K timed steps;
+    # a step's NMS runs under the next forward, so the window between the greedy dispatches of steps i0 and i0 + K holds K forwards
+    g = [i for i, (s_, e_, n) in enumerate(rows) if 'greedy_kernel' in n]
+    if len(g) < a.steps + 6:
+        raise SystemExit('trace holds %d NMS dispatches, need %d timed steps + 5' % (len(g), a.steps))
+    seg = rows[g[-6 - a.steps] + 1:g[-6] + 1]
+    tail = [(e_ - s_) / 1e3 for s_, e_, n in seg if CONV3.search(n)]
+    per_step = len(tail) / a.steps
     us_step = sum(tail) / a.steps
     ach = flops_step / (us_step * 1e-6) / 1e12
     print(json.dumps({
         'kernel_source_hash': source_hash(), 'workload': d['config']['workload'],
         'kernel': '3x3 convolution layers: every dispatch of conv3x3_*kernel / stem2_fused_kernel / stem_planar_kernel / pw_s2_fused_kernel / '
                   'conv_mfma_kernel<KS=3> in the timed steps of a rocprofv3 --kernel-trace of bench.py --inflight 1',
-        'steps': a.steps, 'dispatches_per_step': per_step, 'layers_per_step': r['launches'],
+        'steps': a.steps, 'dispatches_per_step': round(per_step, 2), 'layers_per_step': r['launches'],
         'conv3_us_per_step': round(us_step, 1), 'avg_dispatch_us': round(sum(tail) / len(tail), 2),
         'flops_per_step': flops_step, 'achieved_tflops': round(ach, 1), 'peak_tflops': a.peak, 'frac': round(ach / a.peak, 4),
         'bench_event_timed_frac': r.get('frac_event', r['frac']), 'bench_value_inflight1': d.get('value_inflight1')}))
