@@ -1017,7 +1017,8 @@ extern "C" int lp_engine_set_graph(lp_engine* e, int enable) {
 
 // Marks the end of a forward on the caller's stream with the engine's own event (see lp_engine_destroy).
 static int mark_done(lp_engine* e, hipStream_t st) {
-    if (!e->done_ev) LP_HIP_CHECK(hipEventCreateWithFlags(&e->done_ev, hipEventDisableTiming));
+    // (no system-scope fence: the event orders device work for lp_engine_destroy, nobody reads memory behind it on the host)
+    if (!e->done_ev) LP_HIP_CHECK(hipEventCreateWithFlags(&e->done_ev, hipEventDisableTiming | hipEventDisableSystemFence));
     LP_HIP_CHECK(hipEventRecord(e->done_ev, st));
     e->done_valid = true;
     return LP_OK;
@@ -1031,7 +1032,7 @@ static int mark_done(lp_engine* e, hipStream_t st) {
 static int run_forward(lp_engine* e, const void* x, int x_dtype, float* pred, const DetCtx* det, void* ws, hipStream_t main_st) {
     int rc;
     auto issue = [&](hipStream_t st) -> int {
-        if (det) LP_HIP_CHECK(hipMemsetAsync(det->w.cnt, 0, (size_t)e->B * 4, st));   // BEFORE the lanes fork: every head op comes behind it
+        if (det) { if (int zr = zero_counts_launch(det->w.cnt, e->B, st)) return zr; }   // BEFORE the lanes fork: every head op comes behind it
         return issue_forward(e, x, x_dtype, pred, st, det);
     };
     if (!e->use_graph) {

@@ -149,6 +149,7 @@ NmsWs nms_carve(void* base, int B, int N);
 // score_kernel over `rows_per_img` prediction rows per image (row stride 290 floats, images `rows_per_img` rows apart) whose
 // anchors are anchor0.. of N: appends the candidates; write_box false leaves columns 0..11 of the candidate rows alone.
 int nms_score_launch(float* pred, int B, int rows_per_img, int anchor0, int N, float conf_f, const NmsWs& w, bool write_box, hipStream_t st);
+int zero_counts_launch(int* p, int n, hipStream_t st);   // p[0..n) = 0 by a kernel of our own (no hipMemsetAsync: see lp_nms.hip)
 
 // ---- auxiliary kernels ----------------------------------------------------------------------------
 int input_launch(const void* x, int x_dtype, void* dst, int dtype, int B, int H, int W, hipStream_t st);

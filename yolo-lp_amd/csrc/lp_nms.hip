@@ -508,6 +508,20 @@ extern "C" int lp_check_iou_predicate(const float* dev_pairs, long long n, doubl
     return LP_OK;
 }
 
+// Zeroes the per-image candidate counters.  A kernel of our own, not hipMemsetAsync: the runtime's fill is a blit kernel with
+// barrier packets around it (the device sat idle 16-38 us in front of it at every step boundary, tools/micro/fwd_idle.py).
+namespace lp {
+__global__ void zero_counts_kernel(int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+int zero_counts_launch(int* p, int n, hipStream_t st) {
+    hipLaunchKernelGGL(zero_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
+}
+}  // namespace lp
+
 extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_thres, int max_det, float* det,
                       int32_t* count, int32_t* keep, void* workspace, size_t workspace_bytes, void* stream) {
     if (!pred || !det || !count || !workspace) return fail(LP_ERR_ARG, "lp_nms: null pointer");
@@ -523,7 +537,7 @@ extern "C" int lp_nms(float* pred, int B, int N, double conf_thres, double iou_t
     float thr_f = (float)iou_thres;                       // largest fp32 not above the double threshold
     if ((double)thr_f > iou_thres) thr_f = nextafterf(thr_f, -INFINITY);
 
-    LP_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st));
+    if (int rc = zero_counts_launch(w.cnt, B, st)) return rc;
     if (int rc = nms_score_launch(pred, B, N, 0, N, conf_f, w, true, st)) return rc;
     return sort_greedy_launch(w, B, N, thr_f, max_det, det, count, keep, st);
 }

@@ -84,8 +84,7 @@ class Engine:
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
         self.single_lane = False   # set_single_lane
         self.fuse_siblings = os.environ.get('LP_NO_SIBLINGS') is None   # sibling layers on one input as one launch (conv_pair)
-        self._last_stream = None   # stream + event of the last forward: a forward on ANOTHER stream waits for it (one arena)
-        self._last_event = None
+        self._last_stream = None   # stream of the last forward: a forward on ANOTHER stream waits for it (one arena)
         self._graph_pred = None
         self._graph_x = None       # graph mode: persistent staging copy of the input (fixed address)
         self.det_crossover = DET_CROSSOVER   # `detect`: candidate density above which forward + lp_nms is the faster form
@@ -397,17 +396,15 @@ class Engine:
 
     def _stream_enter(self):
         """The engine has ONE activation arena: a forward issued on another stream than the previous one (the model's
-        one-at-a-time callers and an InflightForward slot share engine 0) first waits for that one to finish."""
+        one-at-a-time callers and an InflightForward slot share engine 0) first waits for what that stream holds.  (No event
+        per forward: an event record is a barrier packet with a system-scope fence, ~10 us at the start of the next forward.)"""
         cur = torch.cuda.current_stream(self.device)
-        if self._last_event is not None and self._last_stream != cur.cuda_stream:
-            cur.wait_event(self._last_event)
+        if self._last_stream is not None and self._last_stream.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(self._last_stream)
         return cur
 
     def _stream_leave(self, cur):
-        if self._last_event is None:
-            self._last_event = torch.cuda.Event()
-        self._last_event.record(cur)
-        self._last_stream = cur.cuda_stream
+        self._last_stream = cur
 
     def set_single_lane(self, enable=True):
         """Issue every kernel of a forward on the caller's stream (no side lanes): what several forwards in flight on several
