@@ -48,8 +48,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--detail', default='', help='write the per-op device-time table to this file')
     ap.add_argument('--single-lane', type=int, default=-1, help='1: every engine issues its kernels on ONE stream (no side lanes for '
-                    'independent branches); 0: up to three lanes per forward; default: 1 with several batches in flight, else 0 '
-                    '(profiles/r03_inflight_lanes.txt)')
+                    'independent branches; the default); 0: up to three lanes per forward '
+                    '(profiles/r03_inflight_lanes.txt, profiles/r03_round_ab.txt)')
     ap.add_argument('--roofline-file', default=os.path.join(ROOT, 'profiles', 'r03_roofline.json'),
                     help='roofline of the 3x3 layers from a rocprofv3 --kernel-trace of this command (tools/roofline_from_trace.py); '
                          'reported as roofline.frac when its kernel-source hash equals that of this build')
@@ -176,7 +176,7 @@ def main():
                 handle, ready, release = pipe.submit_det(xs[k], args.conf, fresh=False)
             s_post.wait_event(ready)
         else:
-            eng.set_single_lane(args.single_lane == 1)              # one batch in flight: the lanes of a forward overlap its branches
+            eng.set_single_lane(args.single_lane != 0)              # (--single-lane 0: independent branches of a forward on side streams)
             if args.via_pred:
                 pred = eng.forward(x)
             else:

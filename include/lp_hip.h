@@ -144,11 +144,12 @@ int lp_engine_forward_det(lp_engine* e, const void* x, int x_dtype, double conf_
  * launch-bound shapes (batch 1). */
 int lp_engine_set_graph(lp_engine* e, int enable);
 
-/* enable != 0: the forwards issue every kernel on the caller's stream in op order; 0 (default): independent branches of the
- * graph (lp_engine_set_lane) run on side streams forked from / joined into the caller's stream.  The lanes shorten ONE forward
- * (+2.6 % at one batch in flight); with several forwards in flight on several streams their fork / join events cost more than
- * they hide (six batches in flight: 16.2 k images/s on one lane each against 14.9 k; profiles/r03_inflight_lanes.txt), so
- * InflightForward switches them off.  Results do not depend on it. */
+/* enable != 0 (default): the forwards issue every kernel on the caller's stream in op order; 0: independent branches of the
+ * graph (lp_engine_set_lane) run on side streams forked from / joined into the caller's stream.  With several forwards in flight
+ * on several streams the fork / join events cost more than the lanes hide (six batches in flight: 16.2 k images/s on one lane
+ * each against 14.9 k; profiles/r03_inflight_lanes.txt); with ONE forward in flight the lanes were worth +2.6 % until the head
+ * kernels got shorter -- final state of round 3: one lane +1.2 % at batch 32, +4.5 % at batch 1, lanes +1.8 % on yolov6m 1280x1280
+ * (profiles/r03_round_ab.txt).  Results do not depend on it. */
 int lp_engine_set_single_lane(lp_engine* e, int enable);
 
 /* Introspection for benchmarks: ops of the frozen graph and per-op device time (hipEvent pairs on

@@ -905,6 +905,33 @@ def test_engines_dropped_with_work_in_flight():
         assert torch.equal(p, ref)
 
 
+def test_execution_lanes_give_the_same_bits_as_one_lane():
+    """One lane is the default since round 3; the side lanes (independent branches of the graph on forked streams) stay
+    selectable and must not change a bit, in the plain and in the detections-only forward, also with a graph replay."""
+    from yolov6.hip import runtime
+    from yolov6.utils.synth import build_synthetic
+    for name in ('yololps', 'yolov6m'):
+        m = build_synthetic(CFG(name), width=0.125, sigma=1.5).cuda().half()
+        x = torch.rand(4, 3, 192, 256, generator=torch.Generator().manual_seed(5)).cuda().half()
+        with torch.no_grad():
+            eng = runtime.engine_for(m)
+            assert eng.single_lane
+            ref = m(x)[0].clone()
+            det_ref = [t.clone() for t in runtime.detect_padded(m, x, 0.05, 0.45, 300, route='det')[:2]]
+            eng.set_single_lane(False)
+            got = m(x)[0].clone()
+            det = runtime.detect_padded(m, x, 0.05, 0.45, 300, route='det')[:2]
+            assert torch.equal(got, ref), name
+            assert torch.equal(det[0], det_ref[0]) and torch.equal(det[1], det_ref[1]), name
+            m.lp_graph = True                       # (what Inferer sets: the forward replayed as one hipGraph, lanes captured)
+            got = m(x)[0].clone()
+            got2 = m(x)[0].clone()
+            m.lp_graph = False
+            eng.set_single_lane(True)
+            assert torch.equal(got, ref) and torch.equal(got2, ref), name
+        assert int(det_ref[1].sum()) > 0
+
+
 def test_nms_on_two_streams_at_once():
     """The NMS workspace is per (device, stream): two streams post-processing different batches must not share one."""
     from yolov6.hip.runtime import nms_padded

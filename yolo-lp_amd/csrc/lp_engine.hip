@@ -95,7 +95,7 @@ struct lp_engine {
     hipStream_t lane_stream[LP_MAX_LANES] = {};   // [0] = the caller's stream
     std::vector<hipEvent_t> op_event; // per op, created lazily for ops with signal
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
-    bool single_lane = false;         // lp_engine_set_single_lane: every op on the caller's stream, in op order
+    bool single_lane = true;          // lp_engine_set_single_lane (default): every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
     struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
         hipGraphExec_t exec = nullptr;

@@ -29,7 +29,7 @@ class InflightForward:
         torch.cuda.synchronize(self.device)     # the engines' packed weights are uploaded before any side stream uses them
         # several forwards in flight: each on ONE stream (the fork / join events of the side lanes cost more than they hide
         # once other batches fill the gaps: six in flight 16.2 k images/s against 14.9 k, profiles/r03_inflight_lanes.txt)
-        self.single_lane = (self.depth > 1) if single_lane is None else bool(single_lane)
+        self.single_lane = True if single_lane is None else bool(single_lane)
         self._next = 0
         self._ws = [None] * self.depth          # detections-only path: one NMS workspace per engine ...
         self._ws_free = [None] * self.depth     # ... and the event after which its previous candidates are no longer needed

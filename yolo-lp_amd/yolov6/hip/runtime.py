@@ -82,7 +82,7 @@ class Engine:
         self.autotune = os.environ.get('LP_AUTOTUNE', '1') != '0'
         self.max_tuned_shapes = 32   # a directory of oddly sized frames must not pay the tuner for every new shape
         self.graph = False         # hipGraph replay of the forward (set_graph); pred is then a persistent buffer
-        self.single_lane = False   # set_single_lane
+        self.single_lane = True    # set_single_lane (the library's default; LP_LANES=1: execution lanes on)
         self.fuse_siblings = os.environ.get('LP_NO_SIBLINGS') is None   # sibling layers on one input as one launch (conv_pair)
         self._last_stream = None   # stream of the last forward: a forward on ANOTHER stream waits for it (one arena)
         self._graph_pred = None
@@ -93,6 +93,8 @@ class Engine:
         self.det_routes = {'det': 0, 'pred': 0}   # how often `detect` took each form (introspection / tests)
         self.input_id = self.tensor(3, 0)
         abi.check(self.lib.lp_engine_add_input(self.h, self.input_id), 'lp_engine_add_input')
+        if os.environ.get('LP_LANES'):
+            self.set_single_lane(False)
 
     @classmethod
     def from_model(cls, model, dtype, device):
@@ -408,7 +410,8 @@ class Engine:
 
     def set_single_lane(self, enable=True):
         """Issue every kernel of a forward on the caller's stream (no side lanes): what several forwards in flight on several
-        streams want (lp_engine_set_single_lane); one forward at a time is 2-3 % faster with the lanes."""
+        streams want (lp_engine_set_single_lane), and the default; ``False``: independent branches on side streams (worth
+        +1.8 % for one yolov6m 1280x1280 batch at a time, -1 ... -4 % elsewhere: profiles/r03_round_ab.txt)."""
         if bool(enable) != self.single_lane:
             self.single_lane = bool(enable)
             abi.check(self.lib.lp_engine_set_single_lane(self.h, 1 if enable else 0), 'lp_engine_set_single_lane')
