@@ -20,6 +20,9 @@ int conv_pipe_launch_bf16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st);
 int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st);
 int head_rows_launch_bf16(const ConvArgs& a, int cb_pack, hipStream_t st);
 int head_rows_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_box_det_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_box_det_launch_bf16(const ConvArgs& a, int cb_pack, hipStream_t st);
+int head_box_det_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st);
 
 ConvShape conv_shape(int dtype, int cfg, int ksize, int stride) {
     const int sz = (int)dtype_size(dtype);
@@ -276,6 +279,23 @@ bool head_det_fits(int dtype, int nchunks, int cb_pack, int out_c) {
     const long lds = (long)nchunks * 9 * 32 * 128 + 9 * 32 * 4 + 32 * 8 * 4 + 16 + 6 * 32 * 8 * 4 + 6 * 1168;
     return nchunks >= 1 && nchunks <= (dtype == LP_F32 ? 3 : 4) && lds <= 160 * 1024 && (cb_pack == 32 || cb_pack == 64 || cb_pack == 128) &&
            out_c == LP_PRED_COLS - 13;
+}
+
+// Streaming form of the box / corner predictors in the detections-only forward (lp_head_box.inc): whether the op fits, and the launch.
+bool head_box_det_fits(const ConvArgs& a, int cb_pack, int ksize, int stride) {
+    const int nchunks = a.chunk_begin[a.nsrc];
+    return ksize == 1 && stride == 1 && a.nsrc == 1 && nchunks >= 1 && nchunks <= 4 && a.reg_bins == 1 && a.out_c == 12 && a.nct == 1 &&
+           cb_pack >= 32 && a.nphase == 1 && a.out_scale == 1 && a.Ho == a.H && a.Wo == a.W && a.src[0].cs % 8 == 0;
+}
+int head_box_det_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) {
+    if (!a.det_mode || !a.out || !a.zero || !head_box_det_fits(a, cb_pack, 1, 1)) return fail(LP_ERR_ARG, "head box: op does not fit");
+    if (a.out_pix_stride % 4 != 0 || a.out_img_stride % 4 != 0 || ((uintptr_t)a.out & 15)) return fail(LP_ERR_ARG, "head box: candidate rows are not 16-byte aligned");
+    switch (dtype) {
+        case LP_F16: return head_box_det_launch_f16(a, cb_pack, st);
+        case LP_BF16: return head_box_det_launch_bf16(a, cb_pack, st);
+        case LP_F32: return head_box_det_launch_f32(a, cb_pack, st);
+    }
+    return fail(LP_ERR_ARG, "head box: dtype");
 }
 
 int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) {

@@ -2,6 +2,7 @@
 #include "lp_conv_kernel.inc"
 #include "lp_conv1x1_stream.inc"
 #include "lp_head_rows.inc"
+#include "lp_head_box.inc"
 #include "lp_conv3x3_pipe.inc"
 #include "lp_conv3x3_pipel.inc"
 #include "lp_stem_planar.inc"
@@ -16,6 +17,7 @@ int conv_stream_launch_f16(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
     return stream_launch_dtype<f16>(wc, a, cb_pack, lds, st);
 }
 int head_rows_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_rows_launch_dtype<f16>(a, cb_pack, st); }
+int head_box_det_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_box_det_launch_dtype<f16>(a, cb_pack, st); }
 int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) {
     if (pcfg == PIPE_FUSED2) return stem2_fused_launch<f16>(a, ncu, st);
     if (pcfg == PIPE_FUSED_PW) return pw_s2_fused_launch<f16>(a, ncu, st);

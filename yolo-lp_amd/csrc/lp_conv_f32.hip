@@ -2,6 +2,7 @@
 #include "lp_conv_kernel.inc"
 #include "lp_conv1x1_stream.inc"
 #include "lp_head_rows.inc"
+#include "lp_head_box.inc"
 
 namespace lp {
 int conv_launch_f32(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
@@ -11,6 +12,7 @@ int conv_stream_launch_f32(int wc, const ConvArgs& a, int cb_pack, int lds, hipS
     return stream_launch_dtype<float>(wc, a, cb_pack, lds, st);
 }
 int head_rows_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_rows_launch_dtype<float>(a, cb_pack, st); }
+int head_box_det_launch_f32(const ConvArgs& a, int cb_pack, hipStream_t st) { return head_box_det_launch_dtype<float>(a, cb_pack, st); }
 
 // Every pair of neighbouring fp32 values a < b (all 2^32 - 1 of them, NaNs skipped): is sigmoid_fast(a) <= sigmoid_fast(b)?
 // The detections-only head relies on it (lp_head_rows.inc: largest sigmoid of a head = sigmoid of its largest logit).

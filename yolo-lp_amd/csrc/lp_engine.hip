@@ -888,6 +888,8 @@ static int run_head_det(lp_engine* e, size_t idx, const DetCtx& dc, hipStream_t 
         a.out = dc.w.rows + (long long)anchor0 * LP_DET_COLS;
         a.out_pix_stride = LP_DET_COLS;
         a.out_img_stride = (long long)N * LP_DET_COLS;
+        static const bool no_box_stream = getenv("LP_NO_BOX_STREAM") != nullptr;     // (A/B switch: the generic decode kernel)
+        if (!no_box_stream && head_box_det_fits(a, L.cb_pack, L.ks, L.st)) return head_box_det_launch(dt, a, L.cb_pack, st);
         return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
     }
     if (op.det_scratch == (size_t)-1) {     // class predictors + candidate selection in one kernel

@@ -133,6 +133,8 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st);
 // Row-writer form of the class predictors (lp_head_rows.inc).
 bool head_rows_fits(int dtype, int nchunks, int cb_pack, int out_c);
 bool head_det_fits(int dtype, int nchunks, int cb_pack, int out_c);   // its detections-only form (head_det_kernel)
+bool head_box_det_fits(const ConvArgs& a, int cb_pack, int ksize, int stride);
+int head_box_det_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);   // box / corner predictors of the detections-only forward, streaming form
 int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st);   // a.det_mode: the candidate-writing form
 
 // ---- post-processing pieces shared with the engine's detections-only forward (lp_nms.hip) ----
