@@ -130,8 +130,8 @@ template <> struct Max8<f16> {
 
 // One workgroup per (image, GP granules = 8*GP channels): the plane sits in LDS, three chained separable 5x5 passes.
 // A work item is (pixel, granule), so neighbouring lanes move neighbouring 16-B pieces of a pixel's channel run.
-template <typename T>
-__global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void pool_chain_kernel(const T* __restrict__ src, T* __restrict__ d1, T* __restrict__ d2,
                                                         T* __restrict__ d3, int h, int w, int cs, int gp_log2, unsigned w_magic) {
     typedef T V8 __attribute__((ext_vector_type(8)));          // the 8 channels of one granule: 16 B (fp32: 32 B)
     extern __shared__ __attribute__((aligned(16))) char pool_smem[];
@@ -148,23 +148,23 @@ __global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ s
     const int groups = cs / (8 * GP);
     const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
     const long long base = (long long)b * hw * cs + cg * 8 * GP;
-    for (int i0 = threadIdx.x; i0 < items; i0 += 256 * 8) {      // eight loads in flight per thread, then the LDS writes
+    for (int i0 = threadIdx.x; i0 < items; i0 += NT * 8) {      // eight loads in flight per thread, then the LDS writes
         V8 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k * 256;
+            const int i = i0 + k * NT;
             const int ic = i < items ? i : items - 1;
             const int p = ic >> gp_log2, g = ic & (GP - 1);
             v[k] = *(const V8*)(src + base + (long long)p * cs + g * 8);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (i0 + k * 256 < items) cur[i0 + k * 256] = v[k];
+            if (i0 + k * NT < items) cur[i0 + k * NT] = v[k];
     }
     __syncthreads();
     for (int round = 0; round < 3; ++round) {
         T* const out = round == 0 ? d1 : round == 1 ? d2 : d3;      // (an indexed pointer array would live in scratch memory)
-        for (int i = threadIdx.x; i < items; i += 256) {           // row pass
+        for (int i = threadIdx.x; i < items; i += NT) {           // row pass
             const int p = i >> gp_log2, g = i & (GP - 1);
             const int y = row_of(p), x = p - y * w;
             const int x0 = x - 2 < 0 ? 0 : x - 2, x1 = x + 2 >= w ? w - 1 : x + 2;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void pool_chain_kernel(const T* __restrict__ s
             tmp[i] = m;
         }
         lds_barrier();
-        for (int i = threadIdx.x; i < items; i += 256) {           // column pass
+        for (int i = threadIdx.x; i < items; i += NT) {           // column pass
             const int p = i >> gp_log2, g = i & (GP - 1);
             const int y = row_of(p), x = p - y * w;
             const int y0 = y - 2 < 0 ? 0 : y - 2, y1 = y + 2 >= h ? h - 1 : y + 2;
@@ -200,12 +200,16 @@ static int pool_launch_t(const void* src, void* d1, void* d2, void* d3, int B, i
     int gp_log2 = 0;
     while ((1 << gp_log2) < gp) ++gp_log2;
     const unsigned w_magic = (unsigned)(0x100000000ULL / (unsigned)w) + 1u;
+    // few workgroups with big planes (yolov6m 1280x1280 bs=8: 384 workgroups of 1 600 work items, 50 us): 1 024 threads each
+    const unsigned nwg = (unsigned)(B * (cs / 8 / gp));
+    const bool wide = nwg < 512 && h * w * gp >= 1024;
     if (lds > 48 * 1024) {
-        static std::atomic<unsigned long long> attr_done{0};   // one bit per device
-        if (int rc = set_max_lds_once(pool_chain_kernel<T>, (int)POOL_MAX_LDS, attr_done, "pool")) return rc;
+        static std::atomic<unsigned long long> attr_done{0}, attr_done_w{0};   // one bit per device
+        if (int rc = wide ? set_max_lds_once(pool_chain_kernel<T, 1024>, (int)POOL_MAX_LDS, attr_done_w, "pool")
+                          : set_max_lds_once(pool_chain_kernel<T, 256>, (int)POOL_MAX_LDS, attr_done, "pool")) return rc;
     }
-    hipLaunchKernelGGL((pool_chain_kernel<T>), dim3((unsigned)(B * (cs / 8 / gp))), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2,
-                       (T*)d3, h, w, cs, gp_log2, w_magic);
+    if (wide) hipLaunchKernelGGL((pool_chain_kernel<T, 1024>), dim3(nwg), dim3(1024), lds, st, (const T*)src, (T*)d1, (T*)d2, (T*)d3, h, w, cs, gp_log2, w_magic);
+    else hipLaunchKernelGGL((pool_chain_kernel<T, 256>), dim3(nwg), dim3(256), lds, st, (const T*)src, (T*)d1, (T*)d2, (T*)d3, h, w, cs, gp_log2, w_magic);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(LP_ERR_HIP, std::string("pool launch: ") + hipGetErrorString(e));
     return LP_OK;
