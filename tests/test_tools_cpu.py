@@ -137,3 +137,59 @@ def test_eval_val_cli_reads_labels_and_reports_the_lp_metric(workdir):
     preds, speed, metrics = ev.run(str(img_dir), weights=str(ckpt), batch_size=2, img_size=128, conf_thres=0.03, iou_thres=0.65,
                                    task='val', device='cpu', half=False, save_dir=str(workdir / 'val'), name='exp')
     assert metrics is not None and len(metrics) == 7 and len(metrics[5]) == 10 and 0.0 <= metrics[4] <= 1.0
+
+
+def test_roofline_from_trace_arithmetic(tmp_path):
+    """tools/roofline_from_trace.py (the figure bench.py reports as roofline.frac): on a synthetic kernel trace with known
+    durations it must pick exactly the 3x3 dispatches of the timed steps -- not the warm-up, not the trailing NMS timings --
+    and divide the step's algorithmic FLOPs by their summed duration; tools/micro/fwd_idle.py reads the same trace."""
+    import json
+    import subprocess
+    import sys
+    steps, warm = 4, 3
+    hdr = ['Kind', 'Agent_Id', 'Queue_Id', 'Stream_Id', 'Thread_Id', 'Dispatch_Id', 'Kernel_Id', 'Kernel_Name', 'Correlation_Id',
+           'Start_Timestamp', 'End_Timestamp', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count',
+           'Workgroup_Size_X', 'Workgroup_Size_Y', 'Workgroup_Size_Z', 'Grid_Size_X', 'Grid_Size_Y', 'Grid_Size_Z']
+    rows, t = [], [1000]
+
+    def k(name, us, gap_us=0):
+        t[0] += int(gap_us * 1000)
+        rows.append(['KERNEL_DISPATCH', 'Agent 2', 1, 0, 1, len(rows) + 1, 1, name, len(rows) + 1, t[0], t[0] + int(us * 1000), 0, 0, 64, 0,
+                     32, 256, 1, 1, 65536, 1, 1])
+        t[0] += int(us * 1000)
+
+    def step(scale):
+        k('_ZN2lp18stem2_fused_kernelIDF16_Li2ELi2ELb1EEEvNS_8ConvArgsEi', 80 * scale)
+        k('_ZN2lp19conv3x3_pipe_kernelIDF16_Li0ELb0EEEvNS_8ConvArgsEi', 60 * scale)
+        k('_ZN2lp16conv_mfma_kernelIDF16_Li3ELi3ELi2ELi0ELi2EEEvNS_8ConvArgsE', 40 * scale)      # 3x3 stride 2, generic
+        k('_ZN2lp16conv_mfma_kernelIDF16_Li5ELi1ELi1ELi0ELi2EEEvNS_8ConvArgsE', 15 * scale)      # a 1x1 layer: not counted
+        k('_ZN2lp21conv1x1_stream_kernelIDF16_Li2ELi1ELb0ELb0EEEvNS_8ConvArgsEii', 10 * scale)
+        k('lp::sort_kernel(unsigned long long*, int const*, int)', 5, gap_us=2)
+        k('lp::greedy_kernel(unsigned long long const*, float const*)', 5)
+
+    for _ in range(warm):
+        step(3.0)                        # slow warm-up steps must not enter the figure
+    for _ in range(steps):
+        step(1.0)
+    for _ in range(5):                   # bench.py's five trailing forward + NMS timings
+        step(2.0)
+    d = tmp_path / 'kt'
+    d.mkdir()
+    with open(d / 'x_kernel_trace.csv', 'w') as f:
+        f.write(','.join('"%s"' % h for h in hdr) + '\n')
+        for r in rows:
+            f.write(','.join('"%s"' % v if isinstance(v, str) else str(v) for v in r) + '\n')
+    bench = {'value_inflight1': 1.0, 'config': {'workload': 'synthetic'},
+             'roofline': {'flops_per_launch': 30.0, 'launches': 3, 'frac': 0.5, 'frac_event': 0.5}}
+    (tmp_path / 'bench.json').write_text(json.dumps(bench) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'roofline_from_trace.py'), str(d), str(tmp_path / 'bench.json'),
+                          '--steps', str(steps)], capture_output=True, text=True, check=True).stdout
+    r = json.loads(out)
+    assert r['dispatches_per_step'] == 3.0 and abs(r['conv3_us_per_step'] - 180.0) < 1e-6
+    assert abs(r['achieved_tflops'] - 90e9 / 180e-6 / 1e12) < 0.06 and abs(r['frac'] - 0.2) < 1e-3
+    from yolov6.hip.srchash import source_hash
+    assert r['kernel_source_hash'] == source_hash()
+    idle = subprocess.run([sys.executable, os.path.join(root, 'tools', 'micro', 'fwd_idle.py'), str(d), str(steps)],
+                          capture_output=True, text=True, check=True).stdout
+    assert 'idle 2.0 us' in idle and 'idle before lp::sort_kernel' in idle, idle
