@@ -35,8 +35,6 @@ for nch in (1, 2, 4):
     life = st[:, 8].float()
     print('NCH %d: %d waves, tiles per wave %.2f, life mean %.0f clocks (min %.0f, p50 %.0f, p90 %.0f, max %.0f)' % (
         nch, len(st), tiles.mean(), life.mean(), life.min(), life.median(), life.kthvalue(int(0.9 * len(life))).values, life.max()))
-    wg = life.view(-1, 3).max(1).values
-    print('   life by workgroup index (mean of 8 consecutive groups):', [int(v) for v in wg[:len(wg) // 96 * 96].view(-1, len(wg) // 96 * 96 // 12).mean(1)])
     for k, n in enumerate(names):
         per = st[:, k].float() / (tiles if k < 7 else 1)
         print('  %-26s %8.0f clocks%s   (wave 0: %8.0f, waves 1-2: %8.0f)' % (n, per.mean(), ' per tile' if k < 7 else '         ', per[0::3].mean(), torch.cat([per[1::3], per[2::3]]).mean()))
