@@ -179,8 +179,9 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
        /* pipelined 3x3 stride-1 kernel (persistent, 3-slot LDS ring, nbuf 3): 128 couts x 256 px, 64 x 512, 128 x 128, 32 x 512 */
        LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35,
        LP_VARIANT_PIPE_P = 36 /* 32 x 512, the stem reading the NCHW frame (see above) */,
-       LP_VARIANT_PIPE_DL = 39, LP_VARIANT_PIPE_BL = 40, LP_VARIANT_PIPE_FL = 41 /* PIPE_D / B / F with four loader waves per workgroup that do
-                                       * the LDS-DMA of the ring in place of the eight multiplying waves (nbuf 3) */,
+       LP_VARIANT_PIPE16_D = 39, LP_VARIANT_PIPE16_B = 40, LP_VARIANT_PIPE16_F = 41 /* PIPE_D / B / F on v_mfma_f32_16x16x32 (layers with an even
+                                       * number of 16-channel K-chunks; nbuf 3).  ANOTHER fp32 summation order: equal to the other variants to
+                                       * rounding, not bit for bit -- see lp_engine_set_mfma16 */,
        LP_VARIANT_FUSED_STEM2 = 37 /* op 2 only (3x3 stride 2 behind the stem, <= 64 channels): input op + stem + this layer as ONE kernel
                                       whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */,
        LP_VARIANT_FUSED_PW_S2 = 38 /* a 3x3 stride-2 layer (<= 64 channels) whose input comes from a 1x1 layer (64 -> <= 64 channels) that nobody
@@ -257,6 +258,11 @@ int lp_check_sigmoid_monotone(unsigned long long* dev_violations, void* stream);
  * iou_gt).  Evaluates both forms on n box pairs (device fp32 [n][8]: box i xyxy, box j xyxy); dev_out[k] bit 0 = the product form,
  * bit 1 = the plain division.  Expected: both bits equal for every pair, and equal to the fp32 restatement (tests/test_hip_kernels.py). */
 int lp_check_iou_predicate(const float* dev_pairs, long long n, double iou_thres, unsigned char* dev_out, void* stream);
+
+/* Test hook of the LDS-ring kernels: fills all 160 KiB of LDS of every CU with 0xFFFF halves (NaN in fp16 / bf16).  LDS keeps its
+ * contents between kernels, so a fragment read that runs ahead of its LDS-DMA would otherwise find the (identical) bytes of the
+ * previous launch and go unnoticed; after this call it poisons the output (tests/test_hip_kernels.py). */
+int lp_debug_poison_lds(void* stream);
 
 /* Host-side planning of the frame-reading stem kernels (no device needed; used by the CPU tests): the `choice`-th best output tile
  * TH x TW for an Ho x Wo output map of stem_planar_kernel (fused == 0: TW % 4 == 0, TH * TW <= 512, planar halo within its 20 KiB LDS

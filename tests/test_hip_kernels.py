@@ -31,6 +31,12 @@ def _run(eng, B, H, W):
     return eng.forward(x)
 
 
+def _poison_lds():
+    import ctypes
+    from yolov6.hip import abi
+    abi.check(abi.load().lp_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'lp_debug_poison_lds')
+
+
 def _rand(shape, seed, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -505,17 +511,72 @@ def test_conv3x3_pipe(case, dtype):
         ref = q(ref) + 0.75 * q(res)
     assert rel_err(base.float().cpu(), ref) <= TOL[dtype]
     tried = 0
-    for cfg in (32, 33, 34, 35, 39, 40, 41):          # pipelined variants, without and with loader waves
+    for cfg in (32, 33, 34, 35):                       # the pipelined variants
         try:
             eng.set_variant(op, cfg, 3)
         except RuntimeError:
             continue
         tried += 1
-        for rep in range(2):                               # twice: a stale ring slot or a missed wait shows as run-to-run noise
+        for rep in range(2):
+            # LDS keeps its bytes between kernels: without the poison a fragment read that ran ahead of its LDS-DMA would find
+            # the identical bytes of the launch before and pass
+            _poison_lds()
             eng.tensor_view(dst).fill_(float('nan'))
             _run(eng, B, H, W)
             out = eng.tensor_view(dst)
             assert torch.equal(out, base), (cfg, rep, float((out.float() - base.float()).abs().max()))
+    assert tried >= 1
+
+
+RING_CASES = [
+    # (cin, cout, h, w, B): ONE K-chunk per tile (every chunk of the stream crosses a tile boundary: the DMA tile iterator and the
+    # per-tile halo map advance once per chunk) and at least three tiles per persistent workgroup, ragged maps included
+    (12, 32, 252, 252, 7),        # PIPE_C: 512-pixel tiles
+    (16, 64, 252, 252, 7),        # PIPE_B (64-cout packing)
+    (16, 128, 124, 252, 7),       # PIPE_D / PIPE_F (128-cout packing)
+    (32, 128, 96, 100, 9),        # two chunks per tile: tiles alternate between ring phases
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', RING_CASES, ids=lambda c: '%d-%d-%dx%dx%d' % c)
+def test_conv3x3_pipe_ring_with_poisoned_lds(case, dtype):
+    """the hazard of the one-chunk-per-tile configuration made deterministic.  Every CU's LDS is filled with
+    NaN patterns before each launch, tiles have one (or two) K-chunks so that the ring protocol crosses a tile boundary at every
+    chunk, every workgroup walks >= 3 tiles; three launches per variant must reproduce the generic kernel's bits."""
+    from yolov6.hip import abi
+    cin, cout, h, w, B = case
+    sl = 3
+    eng = _engine(dtype)
+    eng.autotune = False
+    src = eng.tensor(cin, sl)
+    wt = _rand((cout, cin, 3, 3), 1, (2.0 / (cin * 9)) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    dst = eng.conv([src], wt, bias, 3, 1, abi.LP_ACT_RELU, sl)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    x = _rand((B, cin, h, w), 10)
+    _fill(eng, src, x)
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)
+    base = eng.tensor_view(dst).clone()
+    q = lambda t: t.to(dtype).float()
+    ref = F.relu(F.conv2d(q(x), q(wt), bias, padding=1))
+    assert rel_err(base.float().cpu(), ref) <= TOL[dtype]
+    tried = 0
+    for cfg in (32, 33, 34, 35):
+        try:
+            eng.set_variant(op, cfg, 3)
+        except RuntimeError:
+            continue
+        tried += 1
+        for rep in range(3):
+            _poison_lds()
+            eng.tensor_view(dst).fill_(float('nan'))
+            _run(eng, B, H, W)
+            out = eng.tensor_view(dst)
+            assert torch.equal(out, base), (cfg, rep, int((out != base).sum()), int(torch.isnan(out.float()).sum()))
     assert tried >= 1
 
 

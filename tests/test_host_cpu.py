@@ -118,6 +118,125 @@ def test_gather_detections_gloo(tmp_path, world, B):
         assert p.returncode == 0, out.decode()
 
 
+_WORKER_BAD = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from yolov6.core.sharded import gather_detections, ShardSizeError
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'], rank=rank, world_size=world)
+mode = os.environ['LP_TEST_MODE']
+max_det = 4
+b = 3 + (1 if rank == 1 else 0)            # rank 1 holds one image too many
+det = torch.full((b, max_det, 28), float(rank))
+cnt = torch.full((b,), rank + 1, dtype=torch.int32)
+raised = False
+try:
+    if mode == 'global':
+        gather_detections(det, cnt, global_batch=3 * world)
+    elif mode == 'equal':
+        gather_detections(det, cnt)
+    else:                                    # deferred check: gathers without reading the sizes, unpad() raises
+        from yolov6.core.sharded import unpad
+        d, c = gather_detections(det, cnt, global_batch=3 * world, check=False) if rank != 1 else (None, None)
+        if rank == 1:
+            gather_detections(det, cnt, global_batch=3 * world, check=False)
+        unpad(d, c)
+except ShardSizeError as e:
+    raised = True
+    print('rank', rank, 'raised:', e)
+assert raised, 'rank %%d did not see the size mismatch' %% rank
+dist.barrier()                               # every rank is still in step: nobody is stranded in a collective
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+@pytest.mark.parametrize('mode', ['global', 'equal', 'deferred'])
+def test_gather_detections_shard_mismatch_raises_on_every_rank(tmp_path, mode):
+    """VERDICT r3 (ADVICE r2 #4): a rank whose shard has the wrong size must not strand the others in the all-gather.  World 2
+    over gloo, rank 1 holds one image too many: with ``global_batch`` (sizes ride in the count collective), without it (sizes
+    exchanged first) and with the deferred check (``unpad`` reads the sizes); every rank raises ShardSizeError and both reach
+    the barrier behind it."""
+    script = tmp_path / 'worker_bad.py'
+    script.write_text(_WORKER_BAD % REPO)
+    port = str(29500 + (os.getpid() * 11 + len(mode) * 17) % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port, LP_TEST_MODE=mode)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError('a rank hung in the collective (mode %s)' % mode)
+        assert p.returncode == 0, out.decode()
+
+
+_LISTING = """
+\t.text
+_Z6kernelv: ; @_Z6kernelv
+\ts_load_dword s4, s[0:1], 0x0
+\ts_waitcnt lgkmcnt(0)
+.LBB0_1:
+\t;;#ASMSTART
+\tds_read_b128 v[4:7], v0 offset:0
+\t;;#ASMEND
+\t;;#ASMSTART
+\tds_read_b128 v[8:11], v0 offset:16
+\t;;#ASMEND
+%s
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(1)
+\t;;#ASMEND
+\tv_mfma_f32_32x32x16_f16 v[16:31], v[4:7], v[4:7], v[16:31]
+%s
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_asm_audit_finds_the_hazards_it_is_meant_for(tmp_path):
+    """tools/asm_audit.py on synthetic listings: a clean hand-counted read pipeline passes; a compiler copy of a register whose
+    LDS read is in flight, an MFMA on a fragment the counted wait does not cover, and a counted wait with a scalar load pending
+    are each reported (the hazard classes behind VERDICT r3 'What's weak' 1)."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import asm_audit
+
+    def run(mid, tail):
+        f = tmp_path / 'k.s'
+        f.write_text(_LISTING % (mid, tail))
+        (name, (n, v)), = asm_audit.audit_file(str(f)).items()
+        assert name == '_Z6kernelv' and n >= 6
+        return v
+    assert run('', '\ts_waitcnt lgkmcnt(0)') == []
+    v = run('\tv_mov_b32_e32 v12, v9', '\ts_waitcnt lgkmcnt(0)')                 # copy of an in-flight fragment register
+    assert len(v) == 1 and 'v9' in v[0]
+    v = run('', '\tv_mfma_f32_32x32x16_f16 v[16:31], v[8:11], v[8:11], v[16:31]\n\ts_waitcnt lgkmcnt(0)')   # second read never waited for
+    assert len(v) == 1 and 'v8' in v[0]
+    v = run('\ts_load_dword s5, s[0:1], 0x4', '\ts_waitcnt lgkmcnt(0)')            # SMEM returns out of order: lgkmcnt(1) proves nothing
+    assert any('scalar load' in x for x in v)
+    v = run('', '')                                                                # the loop edge carries the second read into the next pass
+    assert any('v8' in x or 'v9' in x for x in v)
+
+
+def test_hand_scheduled_kernels_of_the_product_build_pass_the_asm_audit():
+    """Every kernel of libyololp_hip.so that waits for inline-asm LDS reads with hand-counted lgkmcnt is disassembled from the
+    shipped binary and audited along all control-flow paths: no instruction may touch a register whose LDS read can still be in
+    flight, no counted wait may be issued with a scalar load pending (DESIGN 3.1d, round 4)."""
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import asm_audit
+    from yolov6.hip import abi
+    pats = ('conv3x3_pipe', 'stem2_fused_kernel', 'pw_s2_fused_kernel', 'stem_planar_kernel', 'head_det_kernel', 'head_cls_rows_kernel',
+            'head_box_det_kernel')
+    res = asm_audit.audit_file(abi.LIB_PATH, pats)
+    assert sum('conv3x3_pipe' in k for k in res) >= 16 and len(res) >= 50, sorted(res)[:5]
+    bad = {k: v[:3] for k, (n, v) in res.items() if v}
+    assert not bad, bad
+
+
 def test_engine_cache_stays_out_of_the_module_state():
     """ADVICE r1: the cached engine must not ride along in ``Model.__dict__`` -- the reference's checkpoint format pickles
     whole modules and EMA / get_model_info deep-copy them (checkpoint.py:22-32)."""

@@ -227,3 +227,34 @@ int pool_launch(const void* src, void* d1, void* d2, void* d3, int dtype, int B,
 }
 
 }  // namespace lp
+
+// ---- test hook: poison the LDS of every CU ----
+// LDS keeps its contents between kernels, and two launches of one kernel on the same data leave in every ring slot exactly the
+// bytes the next launch is about to fetch: a fragment read that runs ahead of its LDS-DMA (a missed or mis-counted wait) then
+// reads stale but CORRECT bytes and the race stays invisible.  This kernel fills all 160 KiB of every CU with 0xFFFF (a NaN in
+// fp16 and bf16) so that any such read poisons the output deterministically (tests/test_hip_kernels.py).
+namespace lp {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_words[];
+    constexpr int NWORDS = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < NWORDS; i += 1024) lds_words[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // keep the stores alive and the workgroup resident for a moment, so that the workgroups of the grid spread over all CUs
+    unsigned acc = 0;
+    for (int i = threadIdx.x; i < NWORDS; i += 1024) acc |= lds_words[i];
+    __builtin_amdgcn_s_sleep(64);
+    if (acc != 0xFFFFFFFFu && sink) sink[0] = acc;
+}
+}  // namespace lp
+
+extern "C" int lp_debug_poison_lds(void* stream) {
+    using namespace lp;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = set_max_lds_once(poison_lds_kernel, 160 * 1024, attr_done, "poison_lds")) return rc;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+    // a workgroup takes a whole CU's LDS, so the dispatcher can place at most one per CU at a time: three rounds of the grid
+    hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)(3 * ncu)), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned*)nullptr);
+    LP_HIP_CHECK(hipGetLastError());
+    return LP_OK;
+}

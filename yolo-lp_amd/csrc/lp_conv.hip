@@ -176,8 +176,8 @@ ConvShape conv_pipe_shape(int pcfg) {
     s.NT = 512;
     s.WP = 2;
     switch (pcfg) {
-        case PIPE_B: case PIPE_BL: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
-        case PIPE_F: case PIPE_FL: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
+        case PIPE_B: case PIPE16_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
+        case PIPE_F: case PIPE16_F: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
         case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
@@ -185,9 +185,10 @@ ConvShape conv_pipe_shape(int pcfg) {
     return s;
 }
 
-bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase) {
+bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase, int nchunks) {
     if (pcfg == PIPE_P) return false;     // the planar stem is chosen by the engine (it replaces the input op as well), never as a variant of a layer
-    if (dtype == LP_F32 || pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_loader(pcfg)) || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
+    if (pipe_is_16(pcfg) && (nchunks < 2 || nchunks % 2 != 0)) return false;   // K-steps pair the taps over two chunks
+    if (dtype == LP_F32 || pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg)) || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
     const ConvShape s = conv_pipe_shape(pcfg);
     return s.CB == cb_pack && nct * s.CB <= 1024;   // 1024 = PIPE_MAXC (bias table in LDS)
 }
@@ -256,7 +257,8 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
     }
     const ConvShape s = conv_pipe_shape(pcfg);
     const int hh = a.TH + 2, hw = a.TW + 2;
-    if (pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_loader(pcfg))) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");
+    if (pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg))) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");
+    if (pipe_is_16(pcfg) && (a.chunk_begin[a.nsrc] < 2 || a.chunk_begin[a.nsrc] % 2 != 0)) return fail(LP_ERR_ARG, "conv3x3 pipe16: odd number of K-chunks");
     if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || a.hpitch < hw || hh * a.hpitch > s.HPMAX)
         return fail(LP_ERR_ARG, "conv3x3 pipe: tile does not fit the kernel configuration");
     if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv3x3 pipe: tiles do not cover the output");

@@ -1257,12 +1257,8 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         int pipe_tile = 0;
         if (!getenv("LP_NO_PIPE") && op.kind == OP_CONV) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.stream_wc = 0;
-            // (the loader-wave form, lp_conv3x3_pipel.inc, measured equal to the plain one at four loader waves and 5-8 % slower at
-            // two: a candidate only on request)
-            static const bool no_loaders = getenv("LP_PIPEL") == nullptr;
-            for (int pc = 0; pc < PIPE_END; ++pc) {
-                if (pc >= PIPE_COUNT && (!pipe_is_loader(pc) || no_loaders)) continue;
-                if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase)) continue;
+            for (int pc = 0; pc < PIPE_COUNT; ++pc) {
+                if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase, op.nchunks)) continue;
                 int last_th = -1, last_tw = -1;
                 for (int tile = 0; tile < 3; ++tile) {
                     op.pipe = pc + 1;
@@ -1453,9 +1449,9 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
         return LP_OK;
     }
     op.planar = 0;
-    if ((cfg >= LP_VARIANT_PIPE_D && cfg < LP_VARIANT_PIPE_D + PIPE_COUNT) || pipe_is_loader(cfg - LP_VARIANT_PIPE_D)) {
+    if ((cfg >= LP_VARIANT_PIPE_D && cfg < LP_VARIANT_PIPE_D + PIPE_COUNT) || pipe_is_16(cfg - LP_VARIANT_PIPE_D)) {
         const int pc = cfg - LP_VARIANT_PIPE_D;
-        if (!conv_pipe_fits(e->dtype, pc, cb, ks, stv, op.mode, op.nct, op.nphase) || op.kind != OP_CONV || nbuf != 3)
+        if (!conv_pipe_fits(e->dtype, pc, cb, ks, stv, op.mode, op.nct, op.nphase, op.nchunks) || op.kind != OP_CONV || nbuf != 3)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: the pipelined 3x3 kernel does not fit this op");
         op.stream_wc = 0;
         op.pipe = pc + 1;

@@ -47,11 +47,9 @@ enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C =
 enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
                  PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
                  PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/,
-                 PIPE_DL = 7, PIPE_BL = 8, PIPE_FL = 9 /*D / B / F with loader waves: lp_conv3x3_pipel.inc*/, PIPE_END = 10 };
-inline bool pipe_is_loader(int pcfg) { return pcfg >= PIPE_DL && pcfg <= PIPE_FL; }
-#ifndef LP_PIPEL_NL
-#define LP_PIPEL_NL 4             // loader waves per workgroup of conv3x3_pipel_kernel (2: 5-8 % slower than the plain kernel, 4: equal, 8: 1.5x slower)
-#endif
+                 PIPE16_D = 7, PIPE16_B = 8, PIPE16_F = 9 /*D / B / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
+                                                            chosen per layer by rule, never by timing*/, PIPE_END = 10 };
+inline bool pipe_is_16(int pcfg) { return pcfg >= PIPE16_D && pcfg <= PIPE16_F; }
 
 struct ConvSrc {
     const void* ptr;
@@ -127,7 +125,7 @@ int conv_stream_launch(int dtype, int wc, const ConvArgs& a, int cb_pack, hipStr
 
 // Pipelined 3x3 stride-1 kernel: geometry of configuration `pcfg` (CB = the weight-packing cout tile it reads), and the launch.
 ConvShape conv_pipe_shape(int pcfg);
-bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase);
+bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase, int nchunks);
 int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st);
 
 // Row-writer form of the class predictors (lp_head_rows.inc).

@@ -12,9 +12,9 @@ LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
 LP_PRED_COLS, LP_DET_COLS, LP_MAX_SRC = 290, 28, 4
 LP_VARIANT_STREAM64, LP_VARIANT_STREAM128, LP_VARIANT_ROWS = 16, 17, 18   # lp_engine_set_op_variant codes beyond the tiles
 LP_VARIANT_PIPE_D, LP_VARIANT_PIPE_B, LP_VARIANT_PIPE_F, LP_VARIANT_PIPE_C = 32, 33, 34, 35        # pipelined 3x3 stride-1 kernel (nbuf 3)
+LP_VARIANT_PIPE16_D, LP_VARIANT_PIPE16_B, LP_VARIANT_PIPE16_F = 39, 40, 41                              # the same on v_mfma_f32_16x16x32 (another fp32 summation order)
 LP_VARIANT_FUSED_PW_S2 = 38                                                                      # a 1x1 layer + the 3x3 stride-2 layer behind it as one kernel
 LP_VARIANT_FUSED_STEM2 = 37                                                                      # input op + stem + the layer behind it as one kernel
-LP_VARIANT_PIPE_DL, LP_VARIANT_PIPE_BL, LP_VARIANT_PIPE_FL = 39, 40, 41                                  # the same with loader waves (lp_conv3x3_pipel.inc)
 LP_VARIANT_PIPE_P = 36                                                                           # the stem reading the NCHW frame itself
 LP_EVAL_NCOUNTS = 43   # lp_eval_counts: length of the counts vector (include/lp_hip.h)
 
@@ -72,6 +72,7 @@ SYMBOLS = {
     'lp_rescale_round': (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     'lp_eval_counts': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'lp_check_sigmoid_monotone': (c_int, [c_void_p, c_void_p]),
+    'lp_debug_poison_lds': (c_int, [c_void_p]),
     'lp_check_iou_predicate': (c_int, [c_void_p, ctypes.c_longlong, c_double, c_void_p, c_void_p]),
     'lp_plan_stem_tile': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
