@@ -15,9 +15,11 @@ DTYPES = [torch.float32, torch.float16, torch.bfloat16]
 TOL = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}
 
 
-def _engine(dtype):
+def _engine(dtype, mfma16=False):
+    """Kernel tests compare variants bit for bit with the default one: the default stays on the 32x32x16 family here; the
+    16x16x32 family (another fp32 summation order) is selected explicitly where it is the subject (LP_VARIANT_PIPE16_*)."""
     from yolov6.hip.runtime import Engine
-    return Engine(dtype, 'cuda:0')
+    return Engine(dtype, 'cuda:0', mfma16=mfma16)
 
 
 def _fill(eng, tid, ref_nchw):
@@ -440,21 +442,33 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
     if use_res:
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
-    base, tried = None, 0
-    for cfg, nb in [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3), (39, 3), (40, 3), (41, 3)]:   # 32..35: LP_VARIANT_PIPE_*, 39..41: with loader waves
-        try:
-            eng.set_variant(op, cfg, nb)
-        except RuntimeError:
-            continue
-        eng.tensor_view(dst).zero_()
-        _run(eng, B, hw << sl, hw << sl)
-        out = eng.tensor_view(dst).clone()
-        tried += 1
-        if base is None:
-            base = out
-        else:
-            assert torch.equal(out, base), (cfg, nb)
-    assert tried >= 2
+    # two families, each bit-identical inside: 32x32x16 (tiles A..F, streaming 1x1, LP_VARIANT_PIPE_*) and 16x16x32
+    # (LP_VARIANT_PIPE16_*: fixed tiles 39..41, tiles of any number of 16-pixel blocks 42..44).  Which family runs a layer is a
+    # function of the layer alone (lp_engine_set_mfma16), so the autotuner's freedom stays inside one family.
+    fam32 = [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3)]
+    fam16 = [(c, 3) for c in (39, 40, 41, 42, 43, 44)]
+    bases = []
+    for fam in (fam32, fam16):
+        base, tried = None, 0
+        for cfg, nb in fam:
+            try:
+                eng.set_variant(op, cfg, nb)
+            except RuntimeError:
+                continue
+            eng.tensor_view(dst).zero_()
+            _run(eng, B, hw << sl, hw << sl)
+            out = eng.tensor_view(dst).clone()
+            tried += 1
+            if base is None:
+                base = out
+            else:
+                assert torch.equal(out, base), (cfg, nb)
+        assert tried >= 2 or fam is fam16
+        bases.append(base)
+    if bases[1] is not None:                                  # the families agree to rounding
+        d = (bases[0].float() - bases[1].float()).abs()
+        assert float(d.max()) <= TOL[dtype] * float(bases[0].float().abs().max())
+        assert k == 3 and s == 1 and cin % 64 == 0
 
 
 PIPE_CASES = [
@@ -526,6 +540,75 @@ def test_conv3x3_pipe(case, dtype):
             out = eng.tensor_view(dst)
             assert torch.equal(out, base), (cfg, rep, float((out.float() - base.float()).abs().max()))
     assert tried >= 1
+
+
+PIPE16_CASES = [
+    # (cin list, cout, act, residual, h, w, B): layers whose K-chunks are a multiple of four (input channels a multiple of 64)
+    ([64], 64, 'relu', False, 160, 160, 3),
+    ([128], 128, 'relu', False, 40, 40, 40),
+    ([256], 256, 'silu', False, 20, 20, 70),
+    ([64, 64], 128, 'relu', False, 40, 40, 20),
+    ([64], 64, 'relu', True, 33, 17, 3),
+    ([128], 72, 'none', False, 13, 27, 5),            # partial cout tile
+    ([512], 512, 'relu', False, 20, 20, 2),
+    ([64], 128, 'relu', False, 124, 252, 2),          # many tiles per workgroup, ragged
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', PIPE16_CASES, ids=lambda c: '%s-%d-%s%s-%dx%dx%d' % ('+'.join(map(str, c[0])), c[1], c[2], '-res' if c[3] else '', c[6], c[4], c[5]))
+def test_conv3x3_pipe16(case, dtype):
+    """The pipelined 3x3 kernel on v_mfma_f32_16x16x32 (LP_VARIANT_PIPE16_*): within the stated tolerance of F.conv2d in fp32 and of
+    the 32x32x16 family (another fp32 summation order, so not bit for bit), its tilings bit-identical among themselves, every
+    launch reproducible with a poisoned LDS ring in front of it."""
+    from yolov6.hip import abi
+    cins, cout, act, use_res, h, w, B = case
+    sl = 5 if h <= 64 else 3
+    eng = _engine(dtype)
+    eng.autotune = False
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, 3, 3), 1, (2.0 / (cin * 9)) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    res_id = eng.tensor(cout, sl) if use_res else None
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, bias, 3, 1, act_id, sl, res=res_id, alpha=0.75)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    xs = [_rand((B, c, h, w), 10 + i) for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()
+    for t, x in zip(srcs, xs):
+        _fill(eng, t, x)
+    res = _rand((B, cout, h, w), 20) if use_res else None
+    if use_res:
+        _fill(eng, res_id, res)
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)
+    base32 = eng.tensor_view(dst).clone()                  # the default variant: 32x32x16 family
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(wt), bias, padding=1)
+    ref = {'none': lambda t: t, 'relu': F.relu, 'silu': F.silu}[act](ref)
+    if use_res:
+        ref = q(ref) + 0.75 * q(res)
+    base16 = None
+    for cfg in (39, 40, 41, 42, 43, 44):               # fixed tiles, then tiles of any number of 16-pixel blocks: the same sums
+        try:
+            eng.set_variant(op, cfg, 3)
+        except RuntimeError:
+            continue
+        for rep in range(2):
+            _poison_lds()
+            eng.tensor_view(dst).fill_(float('nan'))
+            _run(eng, B, H, W)
+            out = eng.tensor_view(dst)
+            if base16 is None:
+                base16 = out.clone()
+                assert rel_err(base16.float().cpu(), ref) <= TOL[dtype], (cfg, rel_err(base16.float().cpu(), ref))
+                # the two families differ by fp32 summation order only: a rounding flip here and there in the 16-bit result
+                d = (base16.float() - base32.float()).abs()
+                assert float(d.max()) <= TOL[dtype] * float(ref.abs().max()) and float((d > 0).float().mean()) < 0.25
+            assert torch.equal(out, base16), (cfg, rep, int((out != base16).sum()), int(torch.isnan(out.float()).sum()))
+    assert base16 is not None
 
 
 RING_CASES = [
@@ -694,7 +777,7 @@ def test_two_destination_conv_equals_two_convs(case, dtype):
     want_a, want_b = eng.tensor_view(ra).clone(), eng.tensor_view(rb).clone()
     assert torch.equal(eng.tensor_view(pa), want_a) and torch.equal(eng.tensor_view(pb), want_b)
     tried = 0
-    variants = [(c, n) for c in range(6) for n in (1, 2)] + ([(16, 2), (17, 2)] if k == 1 else [(32, 3), (33, 3), (34, 3), (35, 3), (39, 3), (40, 3), (41, 3)])
+    variants = [(c, n) for c in range(6) for n in (1, 2)] + ([(16, 2), (17, 2)] if k == 1 else [(32, 3), (33, 3), (34, 3), (35, 3)])
     for cfg, nb in variants:
         try:
             eng.set_variant(op, cfg, nb)
@@ -706,3 +789,15 @@ def test_two_destination_conv_equals_two_convs(case, dtype):
         _run(eng, B, H, W)
         assert torch.equal(eng.tensor_view(pa), want_a) and torch.equal(eng.tensor_view(pb), want_b), (cfg, nb)
     assert tried >= 1
+    # the 16x16x32 family sums in another order: the pair equals the two single layers run in the SAME family, bit for bit
+    for cfg in (39, 40, 41, 42, 43, 44):
+        try:
+            for o in (1, 2, 3):
+                eng.set_variant(o, cfg, 3)
+        except RuntimeError:
+            continue
+        for t in (ra, rb, pa, pb):
+            eng.tensor_view(t).fill_(float('nan'))
+        _run(eng, B, H, W)
+        assert torch.equal(eng.tensor_view(pa), eng.tensor_view(ra)) and torch.equal(eng.tensor_view(pb), eng.tensor_view(rb)), cfg
+        assert rel_err(eng.tensor_view(ra).float().cpu(), want_a.float().cpu()) <= TOL[dtype]

@@ -163,17 +163,17 @@ def dest_regs(inst):
 
 
 def lgkm_entries(inst):
-    """How an instruction enters the LGKM queue: list of (kind, frozenset(dest regs))."""
+    """How an instruction enters the LGKM queue: list of (kind, frozenset(dest regs), source line)."""
     op = inst.op
     if op.startswith('ds_read') or op.startswith('ds_load') or op.startswith('ds_bpermute') or op.startswith('ds_permute') or op.startswith('ds_swizzle'):
-        return [('ds', frozenset(dest_regs(inst)))]
+        return [('ds', frozenset(dest_regs(inst)), inst.line)]
     if op.startswith('ds_'):                     # LDS writes, atomics without return: counted, no destination
-        return [('dsw', frozenset())]
+        return [('dsw', frozenset(), inst.line)]
     if op.startswith('s_load') or op.startswith('s_buffer_load') or op.startswith('s_memtime') or op.startswith('s_memrealtime'):
         n = 2 if op.startswith('s_mem') else 1
-        return [('smem', frozenset())] * n
+        return [('smem', frozenset(), inst.line)] * n
     if op.startswith('s_sendmsg') or op.startswith('s_dcache'):
-        return [('smem', frozenset())]
+        return [('smem', frozenset(), inst.line)]
     return []
 
 
@@ -219,13 +219,13 @@ def audit(insts, labels):
                 s.add(st)
             ins = insts[i]
             pending = set()
-            for kind, regs in q:
+            for kind, regs, _ln in q:
                 pending |= regs
             m = RE_LGKM.search(ins.text) if ins.op == 's_waitcnt' else None
             if ins.op == 's_waitcnt':
                 if m:
                     keep = int(m.group(1))
-                    if keep > 0 and any(k == 'smem' for k, _ in q):
+                    if keep > 0 and any(k == 'smem' for k, _, _ln in q):
                         violations.setdefault(('smem', ins.line), 'line %d: `%s` while a scalar load may be pending (SMEM returns out of order)' % (ins.line, ins.text))
                     if len(q) > keep:
                         q = q[len(q) - keep:] if keep else []
@@ -235,7 +235,9 @@ def audit(insts, labels):
                 hit = touched & pending
                 if hit:
                     who = ', '.join('%s%d' % r for r in sorted(hit))
-                    violations.setdefault(('reg', ins.line), 'line %d: `%s` touches %s while an LDS read into it may be in flight' % (ins.line, ins.text, who))
+                    src = sorted({ln for _k, regs, ln in q if regs & hit})
+                    violations.setdefault(('reg', ins.line), 'line %d: `%s` touches %s while an LDS read into it (issued at line %s) may be in flight' % (
+                        ins.line, ins.text, who, ', '.join(map(str, src))))
                 q.extend(ent)
                 if len(q) > 64:
                     q = q[-64:]

@@ -91,6 +91,73 @@ int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH
     return best;
 }
 
+// The same for the 16x16x32 operand map of conv3x3_pipe16_kernel (3x3 stride 1): lane l = (column i = l & 15, K group g = l >> 4)
+// reads pixel quad_order(i) of a 16-pixel block at tap ta (g < 2) or tb (g >= 2), granule g & 1.
+int conv_pick_pitch16(const ConvShape& s, int TH, int TW) {
+    const int hw = TW + 2, hh = TH + 2, rowb = 32, npix = TH * TW;
+    static const int GRP[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                   {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    auto qo = [](int i) { return ((i >> 2) == 2 ? 12 : (i >> 2) == 3 ? 8 : (i & 12)) + (i & 3); };
+    long best_cost = -1;
+    int best = hw;
+    for (int pitch = hw; pitch < hw + 16; ++pitch) {
+        if (hh * pitch > s.HPMAX) break;
+        long cost = 0;
+        for (int blk = 0; blk * 16 < s.PB; ++blk)
+            for (int st = 0; st < 9; ++st) {
+                const int ta = st < 4 ? 2 * st : (st == 4 ? 8 : 2 * st - 9), tb = st == 4 ? 0 : ta + 1;
+                for (int gq = 0; gq < 4; ++gq) {
+                    int addr[16], n = 0, slot_cnt[16] = {0};
+                    for (int k = 0; k < 16; ++k) {
+                        const int l = GRP[gq][k], i = l & 15, g = l >> 4;
+                        int pl = blk * 16 + qo(i);
+                        if (pl >= npix) pl = 0;
+                        const int ty = pl / TW, tx = pl - ty * TW, t = g < 2 ? ta : tb;
+                        const int hp = (ty + t / 3) * pitch + tx + t % 3;
+                        // (step 4: groups 2 / 3 read another ring slot -- a multiple of 256 bytes away, the same banks)
+                        const int a = hp * rowb + swz_host(hp, g & 1, 2) * 16 + (g >> 1) * (1 << 20);
+                        bool dup = false;
+                        for (int m = 0; m < n; ++m) dup |= addr[m] == a;
+                        if (!dup) { addr[n++] = a; ++slot_cnt[(a >> 4) & 15]; }
+                    }
+                    int mx = 1;
+                    for (int k = 0; k < 16; ++k) mx = slot_cnt[k] > mx ? slot_cnt[k] : mx;
+                    cost += mx;
+                }
+            }
+        cost = cost * 64 + (pitch - hw);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pitch; }
+    }
+    return best;
+}
+
+void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW) {
+    struct Cand { double cost; int th, tw; };
+    Cand best[4];
+    int n = 0;
+    const int ncu = device_cus();
+    for (int th = 1; th <= Ho; ++th)
+        for (int tw = 1; tw <= Wo; ++tw) {
+            if (th * tw > s.PB || (th + 2) * (tw + 2) > s.HPMAX) continue;
+            const long tiles = (long)B * ceil_div(Ho, th) * ceil_div(Wo, tw) * nct;
+            const int nb = ceil_div(th * tw, 16), per_wave = ceil_div(nb, s.WGP);
+            // time ~ (tiles per workgroup) x (K-step length: the busiest wave's blocks + a fixed part) + a little for the halo
+            const double cost = (double)ceil_div((int)tiles, ncu) * (per_wave + 0.75) + 1e-4 * (th + 2) * (tw + 2) + 1e-7 * tiles;
+            int pos = n < 4 ? n : 4;
+            for (int k = 0; k < (n < 4 ? n : 4); ++k)
+                if (cost < best[k].cost) { pos = k; break; }
+            if (pos >= 4) continue;
+            for (int k = (n < 4 ? n : 3); k > pos; --k) best[k] = best[k - 1];
+            best[pos] = {cost, th, tw};
+            if (n < 4) ++n;
+        }
+    if (n == 0) { *TH = 1; *TW = 1; return; }
+    if (choice < 0) choice = 0;
+    if (choice >= n) choice = n - 1;
+    *TH = best[choice].th;
+    *TW = best[choice].tw;
+}
+
 // Candidate output tiles (TH x TW <= PB pixels, halo <= HPMAX), best first: fewest workgroups, then the smallest
 // halo.  `choice` selects the n-th distinct candidate (clamped) -- the autotuner times the first few.
 void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, int choice, int* TH, int* TW) {
@@ -179,6 +246,9 @@ ConvShape conv_pipe_shape(int pcfg) {
         case PIPE_B: case PIPE16_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
         case PIPE_F: case PIPE16_F: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
         case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
+        case PIPE16_V0: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 512; s.PB = 4 * 7 * 16; return s;
+        case PIPE16_V1: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 512; s.PB = 2 * 7 * 16; return s;
+        case PIPE16_V2: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 1088; s.PB = 8 * 7 * 16; return s;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
     s.PB = 32 * s.WP * s.WGP;
@@ -187,14 +257,15 @@ ConvShape conv_pipe_shape(int pcfg) {
 
 bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase, int nchunks) {
     if (pcfg == PIPE_P) return false;     // the planar stem is chosen by the engine (it replaces the input op as well), never as a variant of a layer
-    if (pipe_is_16(pcfg) && (nchunks < 2 || nchunks % 2 != 0)) return false;   // K-steps pair the taps over two chunks
+    if (pipe_is_16(pcfg) && (nchunks < 4 || nchunks % 4 != 0)) return false;   // K-steps pair the taps over two chunks, the loop body is two pairs
     if (dtype == LP_F32 || pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg)) || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
     const ConvShape s = conv_pipe_shape(pcfg);
+    if (pipe_is_16v(pcfg) && (nct * s.CB > 512 || nchunks > 32)) return false;   // PIPE16V_MAXC / PIPE16V_MAXCHUNKS (its LDS tables)
     return s.CB == cb_pack && nct * s.CB <= 1024;   // 1024 = PIPE_MAXC (bias table in LDS)
 }
 
 static int g_ncu[16] = {0};
-static int device_cus() {   // CUs of the current device = persistent workgroups of the pipe kernel (one per CU)
+int device_cus() {   // CUs of the current device = persistent workgroups of the pipe kernel (one per CU)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
     if (!g_ncu[dev]) {
@@ -258,10 +329,11 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
     const ConvShape s = conv_pipe_shape(pcfg);
     const int hh = a.TH + 2, hw = a.TW + 2;
     if (pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg))) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");
-    if (pipe_is_16(pcfg) && (a.chunk_begin[a.nsrc] < 2 || a.chunk_begin[a.nsrc] % 2 != 0)) return fail(LP_ERR_ARG, "conv3x3 pipe16: odd number of K-chunks");
+    if (pipe_is_16(pcfg) && (a.chunk_begin[a.nsrc] < 4 || a.chunk_begin[a.nsrc] % 4 != 0)) return fail(LP_ERR_ARG, "conv3x3 pipe16: K-chunks not a multiple of four");
     if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || a.hpitch < hw || hh * a.hpitch > s.HPMAX)
         return fail(LP_ERR_ARG, "conv3x3 pipe: tile does not fit the kernel configuration");
     if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv3x3 pipe: tiles do not cover the output");
+    if (pipe_is_16v(pcfg) && (a.nct * s.CB > 512 || a.chunk_begin[a.nsrc] > 32)) return fail(LP_ERR_ARG, "conv3x3 pipe16v: layer exceeds the kernel's LDS tables");
     if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nct * s.CB > 1024 || a.nphase != 1 || a.out_scale != 1 || a.Ho != a.H || a.Wo != a.W)
         return fail(LP_ERR_ARG, "conv3x3 pipe: not a 3x3 stride-1 layer this kernel runs");
     switch (dtype) {

@@ -73,6 +73,9 @@ struct Launch {
 }  // namespace lp
 
 using namespace lp;
+struct lp_engine;
+static bool op_fam16(const lp_engine* e, const lp::Op& op);
+static int fam16_default_pipe(const lp_engine* e, const lp::Op& op);
 
 #ifndef LP_MAX_LANES
 #define LP_MAX_LANES 5
@@ -97,6 +100,7 @@ struct lp_engine {
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
     bool single_lane = true;          // lp_engine_set_single_lane (default): every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
+    bool mfma16 = getenv("LP_NO_MFMA16") == nullptr;   // lp_engine_set_mfma16: eligible 3x3 layers run on the 16x16x32 family (op_fam16)
     struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
         hipGraphExec_t exec = nullptr;
         const void* x = nullptr;
@@ -455,6 +459,7 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         }
         for (int i = op.nsrc; i < LP_MAX_SRC; ++i) op.chunk_begin[i + 1] = op.chunk_begin[op.nsrc];
         op.nchunks = op.chunk_begin[op.nsrc];
+        if (op_fam16(e, op)) op.pipe = fam16_default_pipe(e, op);     // the layer's family is fixed here; the autotuner picks inside it
         const int taps = ks * ks;
         const size_t per_phase = (size_t)op.nct * op.nchunks * taps * s.CB * s.KC;
         op.w_phase_stride = (long long)per_phase;
@@ -691,6 +696,17 @@ static bool det_fits(const lp_engine* e, const Op& op) {
     return head_det_fits(e->dtype, op.nchunks, conv_shape(e->dtype, op.cfg, 1, 1).CB, op.cout);
 }
 
+// MFMA family of a layer.  The 16x16x32 kernels (lp_conv3x3_pipe16*.inc) sum in another fp32 order than
+// every other variant, so which family computes a layer must not depend on the batch size or on timing: it is this predicate of the
+// layer alone (3x3 stride 1, 16-bit, K-chunks a multiple of four, 64- / 128-row weight packing).  Inside a family the variants (tile
+// shapes, wave grids) are bit-identical and the autotuner picks by time.
+static bool op_fam16(const lp_engine* e, const Op& op) {
+    if (!e->mfma16 || e->dtype == LP_F32 || op.kind != OP_CONV || op.ksize != 3 || op.stride != 1 || op.mode != MODE_ACT) return false;
+    const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
+    return conv_pipe_fits(e->dtype, cb == 64 ? PIPE16_B : PIPE16_D, cb, 3, 1, op.mode, op.nct, op.nphase, op.nchunks);
+}
+static int fam16_default_pipe(const lp_engine* e, const Op& op) { return (conv_shape(e->dtype, op.cfg, 1, 1).CB == 64 ? PIPE16_B : PIPE16_D) + 1; }
+
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
     ++e->epoch;
@@ -718,8 +734,13 @@ static int prepare_op(lp_engine* e, size_t idx) {
     a.W = s0.w;
     a.Ho = stv == 2 ? s0.h / 2 : s0.h;
     a.Wo = stv == 2 ? s0.w / 2 : s0.w;
-    conv_pick_tile(s, ks, stv, a.Ho, a.Wo, op.tile, &a.TH, &a.TW);
-    a.hpitch = conv_pick_pitch(s, dt, ks, stv, a.TH, a.TW);
+    if (op.pipe && pipe_is_16v(op.pipe - 1)) {
+        conv_pick_tile16v(s, a.Ho, a.Wo, e->B, op.nct, op.tile, &a.TH, &a.TW);
+        a.hpitch = a.TW + 2;      // unswizzled rows: conflict-free for the 16x16 operand map at any pitch
+    } else {
+        conv_pick_tile(s, ks, stv, a.Ho, a.Wo, op.tile, &a.TH, &a.TW);
+        a.hpitch = (op.pipe && pipe_is_16(op.pipe - 1)) ? conv_pick_pitch16(s, a.TH, a.TW) : conv_pick_pitch(s, dt, ks, stv, a.TH, a.TW);
+    }
     a.tw_magic = (unsigned)(((1u << 22) + a.TW - 1) / a.TW);          // n / TW == (n * magic) >> 22 for n * TW < 2^22
     a.hp_magic = (unsigned)(((1u << 22) + a.hpitch - 1) / a.hpitch);
     a.tiles_x = ceil_div(a.Wo, a.TW);
@@ -1011,6 +1032,13 @@ extern "C" int lp_engine_set_single_lane(lp_engine* e, int enable) {
     return LP_OK;
 }
 
+extern "C" int lp_engine_set_mfma16(lp_engine* e, int enable) {
+    if (!e) return fail(LP_ERR_ARG, "lp_engine_set_mfma16: null engine");
+    if (e->finalized) return fail(LP_ERR_STATE, "lp_engine_set_mfma16: the families are fixed by lp_engine_finalize");
+    e->mfma16 = enable != 0;
+    return LP_OK;
+}
+
 extern "C" int lp_engine_set_graph(lp_engine* e, int enable) {
     if (!e) return fail(LP_ERR_ARG, "lp_engine_set_graph: null engine");
     e->use_graph = enable != 0;
@@ -1222,7 +1250,8 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         };
         op.stream_wc = 0;
         op.pipe = 0;
-        for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
+        const bool fam16 = op_fam16(e, op);       // only the 16x16x32 variants are candidates then (another fp32 summation order)
+        for (int cfg = 0; cfg < CFG_COUNT && !fam16; ++cfg) {
             if (conv_shape(e->dtype, cfg, 1, 1).CB != cb) continue;
             for (int nb = 1; nb <= (cfg == CFG_C ? 1 : 2); ++nb) {
                 int last_th = -1, last_tw = -1;
@@ -1240,7 +1269,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             }
         }
         // 1x1 stride-1 layers: the streaming kernel reads the same packing
-        if (!getenv("LP_NO_STREAM")) {
+        if (!getenv("LP_NO_STREAM") && !fam16) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.tile = best_tile;
             for (int wc = 2; wc <= 4; wc += 2) {
                 if (!stream_fits(e, op, wc)) continue;
@@ -1255,9 +1284,9 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         }
         // 3x3 stride-1 layers: the pipelined kernel reads the same packing
         int pipe_tile = 0;
-        if (!getenv("LP_NO_PIPE") && op.kind == OP_CONV) {
+        if ((!getenv("LP_NO_PIPE") || fam16) && op.kind == OP_CONV) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.stream_wc = 0;
-            for (int pc = 0; pc < PIPE_COUNT; ++pc) {
+            for (int pc = fam16 ? PIPE16_D : 0; pc < (fam16 ? PIPE_END : PIPE_COUNT); ++pc) {
                 if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase, op.nchunks)) continue;
                 int last_th = -1, last_tw = -1;
                 for (int tile = 0; tile < 3; ++tile) {
@@ -1272,6 +1301,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
                 }
             }
             op.pipe = 0;
+            if (fam16 && !best_pipe) best_pipe = fam16_default_pipe(e, op);
         }
         if (trc) return fail(trc, "autotune: event timing failed");
         op.cfg = best_cfg;

@@ -48,8 +48,11 @@ enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIP
                  PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
                  PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/,
                  PIPE16_D = 7, PIPE16_B = 8, PIPE16_F = 9 /*D / B / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
-                                                            chosen per layer by rule, never by timing*/, PIPE_END = 10 };
-inline bool pipe_is_16(int pcfg) { return pcfg >= PIPE16_D && pcfg <= PIPE16_F; }
+                                                            chosen per layer by rule, never by timing*/,
+                 PIPE16_V0 = 10, PIPE16_V1 = 11, PIPE16_V2 = 12 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
+                                                                  128 x <= 224, 64 x <= 896*/, PIPE_END = 13 };
+inline bool pipe_is_16(int pcfg) { return pcfg >= PIPE16_D && pcfg <= PIPE16_V2; }
+inline bool pipe_is_16v(int pcfg) { return pcfg >= PIPE16_V0 && pcfg <= PIPE16_V2; }
 
 struct ConvSrc {
     const void* ptr;
@@ -114,6 +117,10 @@ void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, i
 // Halo row pitch (>= halo width) that minimises ds_read_b128 bank conflicts of the pixel-operand reads, found by
 // simulating the LDS banking of every fragment read of the tile (exact model: MI355X_MICROARCH.md, LDS table).
 int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
+int conv_pick_pitch16(const ConvShape& s, int TH, int TW);   // the same for conv3x3_pipe16_kernel's operand map
+// Output tile of conv3x3_pipe16v_kernel (any number of 16-pixel blocks): fewest (rounds of the persistent grid) x (blocks per wave)
+void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW);
+int device_cus();
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 bool stem_planar_tile(int Ho, int Wo, int choice, int* TH, int* TW);   // lp_stem_planar.inc's output tile (choice = k-th best); false: none
 bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch);   // lp_stem2_fused.inc's output tile and stem-tile pitch

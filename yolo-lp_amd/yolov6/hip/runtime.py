@@ -65,7 +65,9 @@ def _folded(m):
 class Engine:
     """One frozen graph + its device buffers for one (model, activation dtype, device)."""
 
-    def __init__(self, dtype, device):
+    def __init__(self, dtype, device, mfma16=None):
+        """mfma16: None = the library's default (on, unless LP_NO_MFMA16 is set); False = every layer on the 32x32x16 MFMA family;
+        True = eligible 3x3 stride-1 layers on v_mfma_f32_16x16x32 (lp_engine_set_mfma16: another fp32 summation order)."""
         self.lib = abi.load()
         self.device = torch.device(device)
         self.dtype = dtype
@@ -73,6 +75,8 @@ class Engine:
         h = ctypes.c_void_p()
         abi.check(self.lib.lp_engine_create(ctypes.byref(h), self.lp_dtype), 'lp_engine_create')
         self.h = h
+        if mfma16 is not None:
+            abi.check(self.lib.lp_engine_set_mfma16(self.h, 1 if mfma16 else 0), 'lp_engine_set_mfma16')
         self._keep = []            # numpy arrays must outlive the add_* calls
         self.bound = None          # (B, H, W)
         self.arena = None
@@ -602,7 +606,7 @@ class Engine:
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
-                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 39: 'Ld', 40: 'Lb', 41: 'Lf'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
+                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 39: 'Md', 40: 'Mb', 41: 'Mf', 42: 'V0', 43: 'V1', 44: 'V2'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
         return ops
 
 
