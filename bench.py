@@ -285,12 +285,26 @@ def main():
         if args.detail:
             with open(args.detail, 'w') as f:
                 for i, o in enumerate(ops):
+                    if o.get('carried_by') is not None:
+                        f.write('%3d %-8s k%d %4d->%4d %s   (runs inside the kernel of op %d: its FLOPs are counted there)\n'
+                                % (i, o['kind'], o['ksize'], o['cin'], o['cout'], o['variant'], o['carried_by']))
+                        continue
                     f.write('%3d %-8s k%d %4d->%4d %s %8.1f us  %7.1f TFLOP/s  %7.1f GB/s (algorithmic)\n'
                             % (i, o['kind'], o['ksize'], o['cin'], o['cout'], o['variant'], o['ms'] * 1e3,
                                o['flops'] / max(o['ms'], 1e-9) / 1e9, o['bytes'] / max(o['ms'], 1e-9) / 1e6))
         conv3 = [o for o in ops if o['kind'] == 'conv' and o['ksize'] == 3]
+        # the backbone alone (north_star's ">= 70 % MFMA roofline on the conv backbone"): all its ops, SURVEY 8(d)'s algorithmic FLOPs
+        nbb = getattr(eng, 'backbone_ops', 0)
+        bb_fl, bb_ms = sum(o['flops_own'] for o in ops[:nbb]), sum(o['ms'] for o in ops[:nbb])
+        KNAME = {'P': 'conv3x3_pipe_kernel', 'M': 'conv3x3_pipe16_kernel', 'V': 'conv3x3_pipe16v_kernel', 'Fz': 'stem2_fused_kernel (stem + the layer behind it)',
+                 'Fp': 'pw_s2_fused_kernel (1x1 + 3x3 stride 2)', 'Pp': 'stem_planar_kernel'}
+        names = {}
+        for o in conv3:
+            v = o['variant']
+            n = KNAME.get(v[:2]) or KNAME.get(v[:1]) or 'conv_mfma_kernel<KS=3>'
+            names[n] = names.get(n, 0) + 1
         allmm = [o for o in ops if o['kind'] in ('conv', 'deconv', 'head_cls', 'head_box')]
-        fl3, ms3 = sum(o['flops'] for o in conv3), sum(o['ms'] for o in conv3)
+        fl3, ms3 = sum(o['flops_own'] for o in conv3), sum(o['ms'] for o in conv3)
         peak = PEAK_TFLOPS[args.dtype]
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         total_ms = sum(o['ms'] for o in ops)
@@ -307,14 +321,17 @@ def main():
         roofline = {
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': traffic, 'traffic_source': traffic_note,
-            'kernel': '3x3 convolution layers (conv3x3_pipe_kernel / conv3x3_s2_kernel / stem2_fused_kernel = stem + the layer behind it / conv_mfma_kernel<KS=3>, implicit GEMM, all %d of a step)' % len(conv3),
+            'kernel': '3x3 convolution layers, implicit GEMM, all %d of a step: %s' % (len(conv3), ', '.join('%s x%d' % kv for kv in sorted(names.items(), key=lambda kv: -kv[1]))),
+            'backbone_frac': round(bb_fl / (bb_ms * 1e-3) / 1e12 / peak, 4) if bb_ms > 0 else None,
+            'backbone': '%d ops, %.3f GFLOP, %.1f us (live hipEvent timing)' % (nbb, bb_fl / 1e9, bb_ms * 1e3),
+            'backbone_flops': bb_fl, 'backbone_dispatches': sum(1 for o in ops[:nbb] if o['ms'] * 1e3 >= 3.0),   # (ops carried by a fused kernel launch nothing)
             'timing': 'hipEvent pairs on the launch stream around %d back-to-back launches of each op' % max(1, args.profile_inner),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
-            'algorithmic_bytes_per_launch': round(sum(o['bytes'] for o in conv3) / max(1, len(conv3))),
-            'all_mfma_kernels_tflops': round(sum(o['flops'] for o in allmm) / (sum(o['ms'] for o in allmm) * 1e-3) / 1e12, 2),
+            'algorithmic_bytes_per_launch': round(sum(o['bytes_own'] for o in conv3) / max(1, len(conv3))),
+            'all_mfma_kernels_tflops': round(sum(o['flops_own'] for o in allmm) / (sum(o['ms'] for o in allmm) * 1e-3) / 1e12, 2),
             'forward_device_ms': round(total_ms, 3), 'nms_device_ms': round(sorted(t_nms)[len(t_nms) // 2], 3),
-            'forward_hbm_gbs': round(sum(o['bytes'] for o in ops) / (total_ms * 1e-3) / 1e9, 1),
+            'forward_hbm_gbs': round(sum(o['bytes_own'] for o in ops) / (total_ms * 1e-3) / 1e9, 1),
         }
         # The headline fraction comes from the kernel trace (rocprofv3 --kernel-trace of this command, one batch in flight:
         # tools/roofline_from_trace.py -> profiles/) when that file was measured on this build's kernel sources; the live
@@ -328,6 +345,9 @@ def main():
                 roofline['achieved_event'] = roofline['achieved']
                 roofline['achieved'], roofline['frac'] = rf['achieved_tflops'], rf['frac']
                 roofline['trace_us_per_step'] = rf['conv3_us_per_step']
+                if rf.get('backbone_frac') is not None:
+                    roofline['backbone_frac_event'] = roofline['backbone_frac']
+                    roofline['backbone_frac'] = rf['backbone_frac']
                 roofline['frac_source'] = '%s (rocprofv3 kernel trace, %d timed steps)' % (os.path.relpath(args.roofline_file, ROOT), rf['steps'])
             else:
                 roofline['frac_source'] = 'live hipEvent timing (stale: %s was measured on kernel sources %s, this build is %s)' % (

@@ -154,7 +154,7 @@ int lp_engine_set_single_lane(lp_engine* e, int enable);
 
 /* MFMA family of the 3x3 stride-1 layers (call before lp_engine_finalize; default: enabled, LP_NO_MFMA16=1 in the environment
  * disables).  enable != 0: every 16-bit 3x3 stride-1 MODE_ACT layer whose 16-channel K-chunks are a multiple of four (input channels
- * a multiple of 64) and whose weights are packed in 64- or 128-row cout tiles runs on v_mfma_f32_16x16x32 (LP_VARIANT_PIPE16_*:
+ * a multiple of 64) and whose weights are packed in 128-row cout tiles (more than 64 stored output channels) runs on v_mfma_f32_16x16x32 (LP_VARIANT_PIPE16_*:
  * tiles of any number of 16-pixel blocks fill the 256 CUs evenly where 256-pixel tiles leave 22 % of the MFMA slots empty).  That
  * family adds the products in another fp32 order than all other variants: results agree to rounding, not bit for bit.  The choice is
  * a function of the layer alone -- never of the batch size, the input size or a timing -- so image k of a batch equals image k
@@ -188,11 +188,11 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
        /* pipelined 3x3 stride-1 kernel (persistent, 3-slot LDS ring, nbuf 3): 128 couts x 256 px, 64 x 512, 128 x 128, 32 x 512 */
        LP_VARIANT_PIPE_D = 32, LP_VARIANT_PIPE_B = 33, LP_VARIANT_PIPE_F = 34, LP_VARIANT_PIPE_C = 35,
        LP_VARIANT_PIPE_P = 36 /* 32 x 512, the stem reading the NCHW frame (see above) */,
-       LP_VARIANT_PIPE16_D = 39, LP_VARIANT_PIPE16_B = 40, LP_VARIANT_PIPE16_F = 41 /* PIPE_D / B / F on v_mfma_f32_16x16x32 (layers with an even
+       LP_VARIANT_PIPE16_D = 39, LP_VARIANT_PIPE16_F = 41 /* PIPE_D / PIPE_F on v_mfma_f32_16x16x32 (128-row packing, layers with a multiple of four
                                        * number of 16-channel K-chunks; nbuf 3).  ANOTHER fp32 summation order: equal to the other variants to
                                        * rounding, not bit for bit -- see lp_engine_set_mfma16 */,
-       LP_VARIANT_PIPE16_V0 = 42, LP_VARIANT_PIPE16_V1 = 43, LP_VARIANT_PIPE16_V2 = 44 /* the same sums as PIPE16_* with tiles of any number of 16-pixel
-                                       * blocks (128 couts x <= 448 px, 128 x <= 224, 64 x <= 896): tiles that fill the persistent grid evenly */,
+       LP_VARIANT_PIPE16_V0 = 42, LP_VARIANT_PIPE16_V1 = 43 /* the same sums as PIPE16_* with tiles of any number of 16-pixel blocks (128 couts x
+                                       * <= 448 px as 2 x 4 waves, 128 x <= 224 as 4 x 2): tiles that fill the persistent grid evenly */,
        LP_VARIANT_FUSED_STEM2 = 37 /* op 2 only (3x3 stride 2 behind the stem, <= 64 channels): input op + stem + this layer as ONE kernel
                                       whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */,
        LP_VARIANT_FUSED_PW_S2 = 38 /* a 3x3 stride-2 layer (<= 64 channels) whose input comes from a 1x1 layer (64 -> <= 64 channels) that nobody

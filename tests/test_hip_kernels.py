@@ -443,10 +443,10 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
         _fill(eng, res_id, _rand((B, cout, hw, hw), 20))
     op = eng.lib.lp_engine_num_ops(eng.h) - 1
     # two families, each bit-identical inside: 32x32x16 (tiles A..F, streaming 1x1, LP_VARIANT_PIPE_*) and 16x16x32
-    # (LP_VARIANT_PIPE16_*: fixed tiles 39..41, tiles of any number of 16-pixel blocks 42..44).  Which family runs a layer is a
+    # (LP_VARIANT_PIPE16_*: fixed tiles 39 / 41, tiles of any number of 16-pixel blocks 42 / 43).  Which family runs a layer is a
     # function of the layer alone (lp_engine_set_mfma16), so the autotuner's freedom stays inside one family.
     fam32 = [(c, n) for c in list(range(8)) + [16, 17] for n in (1, 2)] + [(32, 3), (33, 3), (34, 3), (35, 3)]
-    fam16 = [(c, 3) for c in (39, 40, 41, 42, 43, 44)]
+    fam16 = [(c, 3) for c in (39, 41, 42, 43)]
     bases = []
     for fam in (fam32, fam16):
         base, tried = None, 0
@@ -468,7 +468,7 @@ def test_every_kernel_variant_gives_the_same_bits(shape, act, dtype):
     if bases[1] is not None:                                  # the families agree to rounding
         d = (bases[0].float() - bases[1].float()).abs()
         assert float(d.max()) <= TOL[dtype] * float(bases[0].float().abs().max())
-        assert k == 3 and s == 1 and cin % 64 == 0
+        assert k == 3 and s == 1 and cin % 64 == 0 and cout > 64
 
 
 PIPE_CASES = [
@@ -543,12 +543,12 @@ def test_conv3x3_pipe(case, dtype):
 
 
 PIPE16_CASES = [
-    # (cin list, cout, act, residual, h, w, B): layers whose K-chunks are a multiple of four (input channels a multiple of 64)
-    ([64], 64, 'relu', False, 160, 160, 3),
+    # (cin list, cout, act, residual, h, w, B): layers whose K-chunks are a multiple of four (input channels a multiple of 64) with the 128-row weight packing
+    ([64], 128, 'relu', False, 160, 160, 3),
     ([128], 128, 'relu', False, 40, 40, 40),
     ([256], 256, 'silu', False, 20, 20, 70),
     ([64, 64], 128, 'relu', False, 40, 40, 20),
-    ([64], 64, 'relu', True, 33, 17, 3),
+    ([64], 96, 'relu', True, 33, 17, 3),              # residual, partial cout tile
     ([128], 72, 'none', False, 13, 27, 5),            # partial cout tile
     ([512], 512, 'relu', False, 20, 20, 2),
     ([64], 128, 'relu', False, 124, 252, 2),          # many tiles per workgroup, ragged
@@ -591,7 +591,7 @@ def test_conv3x3_pipe16(case, dtype):
     if use_res:
         ref = q(ref) + 0.75 * q(res)
     base16 = None
-    for cfg in (39, 40, 41, 42, 43, 44):               # fixed tiles, then tiles of any number of 16-pixel blocks: the same sums
+    for cfg in (39, 41, 42, 43):               # fixed tiles, then tiles of any number of 16-pixel blocks: the same sums
         try:
             eng.set_variant(op, cfg, 3)
         except RuntimeError:
@@ -790,7 +790,7 @@ def test_two_destination_conv_equals_two_convs(case, dtype):
         assert torch.equal(eng.tensor_view(pa), want_a) and torch.equal(eng.tensor_view(pb), want_b), (cfg, nb)
     assert tried >= 1
     # the 16x16x32 family sums in another order: the pair equals the two single layers run in the SAME family, bit for bit
-    for cfg in (39, 40, 41, 42, 43, 44):
+    for cfg in (39, 41, 42, 43):
         try:
             for o in (1, 2, 3):
                 eng.set_variant(o, cfg, 3)

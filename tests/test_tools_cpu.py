@@ -180,7 +180,8 @@ def test_roofline_from_trace_arithmetic(tmp_path):
         for r in rows:
             f.write(','.join('"%s"' % v if isinstance(v, str) else str(v) for v in r) + '\n')
     bench = {'value_inflight1': 1.0, 'config': {'workload': 'synthetic'},
-             'roofline': {'flops_per_launch': 30.0, 'launches': 3, 'frac': 0.5, 'frac_event': 0.5}}
+             'roofline': {'flops_per_launch': 30.0, 'launches': 3, 'frac': 0.5, 'frac_event': 0.5,
+                          'backbone_dispatches': 2, 'backbone_flops': 70e9}}      # backbone = the first two forward kernels of a step
     (tmp_path / 'bench.json').write_text(json.dumps(bench) + '\n')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'roofline_from_trace.py'), str(d), str(tmp_path / 'bench.json'),
@@ -188,6 +189,9 @@ def test_roofline_from_trace_arithmetic(tmp_path):
     r = json.loads(out)
     assert r['dispatches_per_step'] == 3.0 and abs(r['conv3_us_per_step'] - 180.0) < 1e-6
     assert abs(r['achieved_tflops'] - 90e9 / 180e-6 / 1e12) < 0.06 and abs(r['frac'] - 0.2) < 1e-3
+    # the backbone fraction: the first two of the five forward kernels of each timed step (80 + 60 us), NMS kernels not counted
+    assert r['forward_dispatches_per_step'] == 5 and abs(r['backbone_us_per_step'] - 140.0) < 1e-6
+    assert abs(r['backbone_frac'] - 70e9 / 140e-6 / 1e12 / 2500.0) < 1e-3
     from yolov6.hip.srchash import source_hash
     assert r['kernel_source_hash'] == source_hash()
     idle = subprocess.run([sys.executable, os.path.join(root, 'tools', 'micro', 'fwd_idle.py'), str(d), str(steps)],

@@ -20,6 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov6.hip.srchash import source_hash   # noqa: E402
 
+NMS = re.compile(r'score_kernel|sort_kernel|greedy_kernel|zero_counts|counts_kernel|nms_')
 CONV3 = re.compile(r'conv3x3_\w*kernel|stem_planar_kernel|stem2_fused_kernel|pw_s2_fused_kernel|conv_mfma_kernelI\w+?Li\dELi3E')
 
 
@@ -44,6 +45,16 @@ def main():
         raise SystemExit('trace holds %d NMS dispatches, need %d timed steps + 5' % (len(g), a.steps))
     seg = rows[g[-6 - a.steps] + 1:g[-6] + 1]
     tail = [(e_ - s_) / 1e3 for s_, e_, n in seg if CONV3.search(n)]
+    # the backbone alone: the first `backbone_dispatches` forward kernels of every timed step (the NMS kernels of the step before run
+    # on the post stream under them and are not forward kernels)
+    bb = None
+    if r.get('backbone_dispatches'):
+        fwd = [(e_ - s_) / 1e3 for s_, e_, n in seg if not NMS.search(n)]
+        per = len(fwd) // a.steps
+        if per * a.steps == len(fwd) and per >= r['backbone_dispatches']:
+            us_bb = sum(sum(fwd[k * per:k * per + r['backbone_dispatches']]) for k in range(a.steps)) / a.steps
+            bb = {'backbone_us_per_step': round(us_bb, 1), 'backbone_dispatches': r['backbone_dispatches'], 'forward_dispatches_per_step': per,
+                  'backbone_frac': round(r['backbone_flops'] / (us_bb * 1e-6) / 1e12 / a.peak, 4)}
     per_step = len(tail) / a.steps
     us_step = sum(tail) / a.steps
     ach = flops_step / (us_step * 1e-6) / 1e12
@@ -54,7 +65,7 @@ def main():
         'steps': a.steps, 'dispatches_per_step': round(per_step, 2), 'layers_per_step': r['launches'],
         'conv3_us_per_step': round(us_step, 1), 'avg_dispatch_us': round(sum(tail) / len(tail), 2),
         'flops_per_step': flops_step, 'achieved_tflops': round(ach, 1), 'peak_tflops': a.peak, 'frac': round(ach / a.peak, 4),
-        'bench_event_timed_frac': r.get('frac_event', r['frac']), 'bench_value_inflight1': d.get('value_inflight1')}))
+        'bench_event_timed_frac': r.get('frac_event', r['frac']), 'bench_value_inflight1': d.get('value_inflight1'), **(bb or {})}))
 
 
 if __name__ == '__main__':

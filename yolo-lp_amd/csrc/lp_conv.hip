@@ -243,12 +243,11 @@ ConvShape conv_pipe_shape(int pcfg) {
     s.NT = 512;
     s.WP = 2;
     switch (pcfg) {
-        case PIPE_B: case PIPE16_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
+        case PIPE_B: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 704; break;
         case PIPE_F: case PIPE16_F: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 384; break;
         case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
         case PIPE16_V0: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 512; s.PB = 4 * 7 * 16; return s;
         case PIPE16_V1: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 512; s.PB = 2 * 7 * 16; return s;
-        case PIPE16_V2: s.CB = 64; s.WGC = 1; s.WGP = 8; s.HPMAX = 1088; s.PB = 8 * 7 * 16; return s;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
     s.PB = 32 * s.WP * s.WGP;

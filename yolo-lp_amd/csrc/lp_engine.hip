@@ -698,14 +698,13 @@ static bool det_fits(const lp_engine* e, const Op& op) {
 
 // MFMA family of a layer.  The 16x16x32 kernels (lp_conv3x3_pipe16*.inc) sum in another fp32 order than
 // every other variant, so which family computes a layer must not depend on the batch size or on timing: it is this predicate of the
-// layer alone (3x3 stride 1, 16-bit, K-chunks a multiple of four, 64- / 128-row weight packing).  Inside a family the variants (tile
+// layer alone (3x3 stride 1, 16-bit, K-chunks a multiple of four, 128-row weight packing: more than 64 stored output channels).  Inside a family the variants (tile
 // shapes, wave grids) are bit-identical and the autotuner picks by time.
 static bool op_fam16(const lp_engine* e, const Op& op) {
     if (!e->mfma16 || e->dtype == LP_F32 || op.kind != OP_CONV || op.ksize != 3 || op.stride != 1 || op.mode != MODE_ACT) return false;
-    const int cb = conv_shape(e->dtype, op.cfg, 1, 1).CB;
-    return conv_pipe_fits(e->dtype, cb == 64 ? PIPE16_B : PIPE16_D, cb, 3, 1, op.mode, op.nct, op.nphase, op.nchunks);
+    return conv_pipe_fits(e->dtype, PIPE16_D, conv_shape(e->dtype, op.cfg, 1, 1).CB, 3, 1, op.mode, op.nct, op.nphase, op.nchunks);
 }
-static int fam16_default_pipe(const lp_engine* e, const Op& op) { return (conv_shape(e->dtype, op.cfg, 1, 1).CB == 64 ? PIPE16_B : PIPE16_D) + 1; }
+static int fam16_default_pipe(const lp_engine*, const Op&) { return PIPE16_D + 1; }
 
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
@@ -1287,6 +1286,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         if ((!getenv("LP_NO_PIPE") || fam16) && op.kind == OP_CONV) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.stream_wc = 0;
             for (int pc = fam16 ? PIPE16_D : 0; pc < (fam16 ? PIPE_END : PIPE_COUNT); ++pc) {
+                if (fam16 && !pipe_is_16(pc)) continue;
                 if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase, op.nchunks)) continue;
                 int last_th = -1, last_tw = -1;
                 for (int tile = 0; tile < 3; ++tile) {

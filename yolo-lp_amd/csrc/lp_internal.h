@@ -47,12 +47,12 @@ enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C =
 enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
                  PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
                  PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/,
-                 PIPE16_D = 7, PIPE16_B = 8, PIPE16_F = 9 /*D / B / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
+                 PIPE16_D = 7, PIPE16_F = 9 /*D / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
                                                             chosen per layer by rule, never by timing*/,
-                 PIPE16_V0 = 10, PIPE16_V1 = 11, PIPE16_V2 = 12 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
-                                                                  128 x <= 224, 64 x <= 896*/, PIPE_END = 13 };
-inline bool pipe_is_16(int pcfg) { return pcfg >= PIPE16_D && pcfg <= PIPE16_V2; }
-inline bool pipe_is_16v(int pcfg) { return pcfg >= PIPE16_V0 && pcfg <= PIPE16_V2; }
+                 PIPE16_V0 = 10, PIPE16_V1 = 11 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
+                                                  128 x <= 224*/, PIPE_END = 12 };
+inline bool pipe_is_16(int pcfg) { return pcfg == PIPE16_D || pcfg == PIPE16_F || pcfg == PIPE16_V0 || pcfg == PIPE16_V1; }
+inline bool pipe_is_16v(int pcfg) { return pcfg == PIPE16_V0 || pcfg == PIPE16_V1; }
 
 struct ConvSrc {
     const void* ptr;

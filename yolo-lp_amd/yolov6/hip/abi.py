@@ -12,8 +12,8 @@ LP_ACT_NONE, LP_ACT_RELU, LP_ACT_SILU = 0, 1, 2
 LP_PRED_COLS, LP_DET_COLS, LP_MAX_SRC = 290, 28, 4
 LP_VARIANT_STREAM64, LP_VARIANT_STREAM128, LP_VARIANT_ROWS = 16, 17, 18   # lp_engine_set_op_variant codes beyond the tiles
 LP_VARIANT_PIPE_D, LP_VARIANT_PIPE_B, LP_VARIANT_PIPE_F, LP_VARIANT_PIPE_C = 32, 33, 34, 35        # pipelined 3x3 stride-1 kernel (nbuf 3)
-LP_VARIANT_PIPE16_D, LP_VARIANT_PIPE16_B, LP_VARIANT_PIPE16_F = 39, 40, 41                              # the same on v_mfma_f32_16x16x32 (another fp32 summation order)
-LP_VARIANT_PIPE16_V0, LP_VARIANT_PIPE16_V1, LP_VARIANT_PIPE16_V2 = 42, 43, 44                           # ... with tiles of any number of 16-pixel blocks
+LP_VARIANT_PIPE16_D, LP_VARIANT_PIPE16_F = 39, 41                              # the same on v_mfma_f32_16x16x32 (another fp32 summation order)
+LP_VARIANT_PIPE16_V0, LP_VARIANT_PIPE16_V1 = 42, 43                           # ... with tiles of any number of 16-pixel blocks
 LP_VARIANT_FUSED_PW_S2 = 38                                                                      # a 1x1 layer + the 3x3 stride-2 layer behind it as one kernel
 LP_VARIANT_FUSED_STEM2 = 37                                                                      # input op + stem + the layer behind it as one kernel
 LP_VARIANT_PIPE_P = 36                                                                           # the stem reading the NCHW frame itself
