@@ -2,7 +2,7 @@
 # Everything profiles/ holds for a round, generated on the GPU box in one go:  bash tools/make_profiles.sh r03
 # (writes gpurun_out/prof_<tag>/; copy what is to be judged into profiles/ afterwards: tools/collect_profiles.sh <tag>)
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
@@ -28,6 +28,9 @@ python3 $root/tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE --ste
 # 4. counters of the pipelined kernel on the 256 -> 256 @ 40x40 layer
 bash $root/tools/micro/pmc_conv.sh $out/pmc_pd3 --batch 32 --k 3 --cin 256 --cout 256 --hw 40 --variant 32,3 > /dev/null 2>&1
 python3 $root/tools/micro/pmc_conv_summary.py $out/pmc_pd3 > $out/pmc_conv_256x256_40_Pd3.txt
+# ... and of the block-tiled 16x16x32 kernel that runs this layer since round 4 (LP_VARIANT_PIPE16_V0)
+bash $root/tools/micro/pmc_conv.sh $out/pmc_v0 --batch 32 --k 3 --cin 256 --cout 256 --hw 40 --variant 42,3 > /dev/null 2>&1
+python3 $root/tools/micro/pmc_conv_summary.py $out/pmc_v0 > $out/pmc_conv_256x256_40_V0.txt
 # 5. the other single-GPU configurations of BASELINE.json: bench lines, per-op tables, kernel-trace summaries
 sec() { python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']

@@ -26,7 +26,7 @@ for f in glob.glob(a.dir + '/**/*kernel_trace.csv', recursive=True):
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         short = re.sub(r'^_ZN2lp\d+', '', n)[:70]
         acc[short].append(us)
-        if 'conv3x3_pipe_kernel' in n or 'stem_planar_kernel' in n or 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n or re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', n):
+        if 'conv3x3_pipe' in n or 'stem_planar_kernel' in n or 'stem2_fused_kernel' in n or 'pw_s2_fused_kernel' in n or re.search(r'conv_mfma_kernelI\w+?Li\dELi3E', n):
             conv3.append(us)
 tot = sum(sum(v) for v in acc.values())
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
