@@ -197,6 +197,12 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
                                       whenever the frame has the engine's 16-bit dtype; the stem's output never reaches memory */,
        LP_VARIANT_FUSED_PW_S2 = 38 /* a 3x3 stride-2 layer (<= 64 channels) whose input comes from a 1x1 layer (64 -> <= 64 channels) that nobody
                                       else reads (BiFusion's downsample(cv2(x)), common.py:504-527): the two as ONE kernel; the 1x1 op is skipped */ };
+/* LP_VARIANT_FUSED_BIFUSION (45): the cv3 of a 64-channel BiFusion level (common.py:504-527: 1x1 ReLU over [upsample(x0), cv1(x1), d]) together with
+ * the transposed convolution and cv1 as ONE kernel (lp_bifusion_fused.inc): their outputs never reach memory; the two carried ops are skipped.
+ * Bit-identical to the three launches.  lp_engine_op_carrier: index of the op whose kernel currently carries `op` (fused stem, fused 1x1 + 3x3
+ * stride 2, fused BiFusion; frame_direct != 0: the caller's frame has the engine's dtype), or -1: the op launches its own kernel. */
+enum { LP_VARIANT_FUSED_BIFUSION = 45 };
+int lp_engine_op_carrier(const lp_engine* e, int op, int frame_direct);
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);
 int lp_engine_set_op_variant(lp_engine* e, int op, int cfg, int nbuf);

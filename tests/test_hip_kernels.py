@@ -736,6 +736,55 @@ def test_iou_predicate_product_form_equals_the_division(iou_thres):
         assert want.any() and not want.all()
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('h,w,B', [(20, 20, 3), (6, 14, 2), (40, 40, 8)])
+def test_bifusion_fused_equals_its_three_ops(h, w, B, dtype):
+    """LP_VARIANT_FUSED_BIFUSION: BiFusion's cv3(cat[upsample(x0), cv1(x1), d]) (common.py:504-527) as one kernel gives the bits of the
+    transposed conv, cv1 and cv3 run as three launches, and matches torch within the stated tolerance.  h x w = the COARSE map."""
+    from yolov6.hip import abi
+    import ctypes
+    from yolov6.hip.runtime import _f32
+    C0, C1, C = 64, 128, 64
+    eng = _engine(dtype)
+    eng.autotune = False
+    sl = 4                                      # coarse level; the fine level is sl - 1
+    x0, x1, d = eng.tensor(C0, sl), eng.tensor(C1, sl - 1), eng.tensor(C, sl - 1)
+    u = eng.tensor(C, sl - 1)
+    wd, bd = _rand((C0, C, 2, 2), 1, (1.0 / C0) ** 0.5), _rand((C,), 2, 0.3)
+    abi.check(eng.lib.lp_engine_add_deconv2x2(eng.h, x0, u, eng._ptr(_f32(wd)), eng._ptr(_f32(bd))))
+    w1, b1 = _rand((C, C1, 1, 1), 3, (2.0 / C1) ** 0.5), _rand((C,), 4, 0.3)
+    a = eng.conv([x1], w1, b1, 1, 1, abi.LP_ACT_RELU, sl - 1)
+    w3, b3 = _rand((C, 3 * C, 1, 1), 5, (2.0 / (3 * C)) ** 0.5), _rand((C,), 6, 0.3)
+    out = eng.conv([u, a, d], w3, b3, 1, 1, abi.LP_ACT_RELU, sl - 1)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    X0, X1, D = _rand((B, C0, h, w), 10), _rand((B, C1, 2 * h, 2 * w), 11), _rand((B, C, 2 * h, 2 * w), 12)
+    for t, x in ((x0, X0), (x1, X1), (d, D)):
+        _fill(eng, t, x)
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)
+    want = eng.tensor_view(out).clone()
+    q = lambda t: t.to(dtype).float()
+    ru = q(F.conv_transpose2d(q(X0), q(wd), bd, stride=2))
+    ra = q(F.relu(F.conv2d(q(X1), q(w1), b1)))
+    ref = F.relu(F.conv2d(torch.cat([ru, ra, q(D)], 1), q(w3), b3))
+    assert rel_err(want.float().cpu(), ref) <= TOL[dtype]
+    eng.set_variant(op, abi.LP_VARIANT_FUSED_BIFUSION, 3)
+    assert eng.lib.lp_engine_op_carrier(eng.h, 1, 0) == op and eng.lib.lp_engine_op_carrier(eng.h, 2, 0) == op      # deconv, cv1 ride along
+    for rep in range(2):
+        for t in (u, a, out):
+            eng.tensor_view(t).fill_(float('nan'))
+        _run(eng, B, H, W)
+        got = eng.tensor_view(out)
+        assert torch.equal(got, want), (rep, int((got != want).sum()), int(torch.isnan(got.float()).sum()))
+        assert torch.isnan(eng.tensor_view(u).float()).all() and torch.isnan(eng.tensor_view(a).float()).all()      # never written: they stay on chip
+    eng.set_variant(op, 1, 1)                   # back to the three launches
+    assert eng.lib.lp_engine_op_carrier(eng.h, 1, 0) == -1
+    _run(eng, B, H, W)
+    assert torch.equal(eng.tensor_view(out), want) and not torch.isnan(eng.tensor_view(u).float()).any()
+
+
 PAIR_CASES = [
     # (cin list, cout1, cout2, k, act, h, w, B): two sibling layers on one input as ONE launch with two destinations
     ([64], 64, 64, 1, 'relu', 40, 24, 2),

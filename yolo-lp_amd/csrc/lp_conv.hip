@@ -318,7 +318,7 @@ bool stem2_fused_tile(int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch)
 }
 
 int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
-    if (pcfg == PIPE_P || pcfg == PIPE_FUSED2 || pcfg == PIPE_FUSED_PW) {   // the fused / planar kernels check their own geometry
+    if (pcfg == PIPE_P || pcfg == PIPE_FUSED2 || pcfg == PIPE_FUSED_PW || pcfg == PIPE_FUSED_BF) {   // the fused / planar kernels check their own geometry
         switch (dtype) {
             case LP_F16: return conv_pipe_launch_f16(pcfg, a, device_cus(), st);
             case LP_BF16: return conv_pipe_launch_bf16(pcfg, a, device_cus(), st);

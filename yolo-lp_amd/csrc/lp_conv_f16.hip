@@ -9,6 +9,7 @@
 #include "lp_stem_planar.inc"
 #include "lp_stem2_fused.inc"
 #include "lp_pw_s2_fused.inc"
+#include "lp_bifusion_fused.inc"
 
 namespace lp {
 int conv_launch_f16(int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st) {
@@ -22,6 +23,7 @@ int head_box_det_launch_f16(const ConvArgs& a, int cb_pack, hipStream_t st) { re
 int conv_pipe_launch_f16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) {
     if (pcfg == PIPE_FUSED2) return stem2_fused_launch<f16>(a, ncu, st);
     if (pcfg == PIPE_FUSED_PW) return pw_s2_fused_launch<f16>(a, ncu, st);
+    if (pcfg == PIPE_FUSED_BF) return bifusion_launch_dtype<f16>(a, ncu, st);
     if (pipe_is_16v(pcfg)) return pipe16v_launch_dtype<f16>(pcfg, a, ncu, st);
     if (pipe_is_16(pcfg)) return pipe16_launch_dtype<f16>(pcfg, a, ncu, st);
     return pcfg == PIPE_P ? stem_planar_launch<f16>(a, ncu, st) : pipe_launch_dtype<f16>(pcfg, a, ncu, st);

@@ -53,6 +53,10 @@ struct Op {
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
     int fused_pw = 0;                   // 3x3 stride-2 layer behind a 1x1 layer (BiFusion's downsample(cv2(x))): != 0: the two run as ONE kernel
                                         // (lp_pw_s2_fused.inc; fused_pw - 1 = its tile choice); the 1x1 op before it is then skipped
+    int fused_bf = 0;                   // BiFusion's cv3 (1x1 over [upsample(x0), cv1(x1), d]): != 0: transposed conv, cv1 and cv3 run as ONE kernel
+                                        // (lp_bifusion_fused.inc); the two ops it carries (bf_up, bf_cv1) are then skipped
+    int bf_up = -1, bf_cv1 = -1;        // ... their indices (lp_engine_finalize: bifusion_fused_possible), and on those ops: bf_carrier = the cv3 op
+    int bf_carrier = -1;
     int fused = 0;                      // ERBlock_2[0] (op 2) only: != 0: when the caller's frame has the engine's dtype, input op, stem and this
                                         // layer run as ONE kernel (lp_stem2_fused.inc; fused - 1 = its tile choice)
     int planar = 0;                     // stem over the space-to-depth image only: != 0: when the caller's frame has the engine's dtype, the
@@ -74,6 +78,7 @@ struct Launch {
 
 using namespace lp;
 struct lp_engine;
+static bool bifusion_fused_possible(const lp_engine* e, size_t i, int* up, int* cv1);
 static bool op_fam16(const lp_engine* e, const lp::Op& op);
 static int fam16_default_pipe(const lp_engine* e, const lp::Op& op);
 
@@ -121,6 +126,7 @@ struct lp_engine {
     Launch stem_planar;               // ops[1] as the PIPE_P kernel (valid when ops[1].planar)
     Launch stem2_fused;               // ops[0..2] as the fused kernel (valid when ops[2].fused)
     std::map<int, Launch> pw_fused;   // op index of the 3x3 layer -> the fused 1x1 + 3x3 launch (valid when that op's fused_pw)
+    std::map<int, Launch> bf_fused;   // op index of BiFusion's cv3 -> the fused launch (valid when that op's fused_bf)
     std::map<std::vector<int>, std::vector<std::vector<int>>> tuned;  // (B,H,W) -> per-op {cfg, nbuf, tile, stream_wc, stream_rd, rows, pipe, planar, fused, fused_pw}
 };
 
@@ -508,6 +514,13 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         std::vector<float>().swap(op.weight);  // the fp32 originals are no longer needed
     }
     align();
+    for (size_t i = 0; i < e->ops.size(); ++i) {       // BiFusion levels whose three 1x1-type ops can run as one kernel (the autotuner decides)
+        int up = -1, c1 = -1;
+        if (!bifusion_fused_possible(e, i, &up, &c1)) continue;
+        e->ops[i].bf_up = up;
+        e->ops[i].bf_cv1 = c1;
+        e->ops[(size_t)up].bf_carrier = e->ops[(size_t)c1].bf_carrier = (int)i;
+    }
     e->finalized = true;
     return LP_OK;
 }
@@ -604,7 +617,7 @@ extern "C" int lp_engine_bind(lp_engine* e, void* dev_arena, size_t bytes, int B
     if (!e->dev_w) return fail(LP_ERR_STATE, "lp_engine_bind: upload the weights first");
     auto it = e->tuned.find({B, H, W});
     if (it != e->tuned.end())
-        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; e->ops[i].fused = it->second[i][8]; e->ops[i].fused_pw = it->second[i][9]; }
+        for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = it->second[i][0]; e->ops[i].nbuf = it->second[i][1]; e->ops[i].tile = it->second[i][2]; e->ops[i].stream_wc = it->second[i][3]; e->ops[i].stream_rd = it->second[i][4]; e->ops[i].rows = it->second[i][5]; e->ops[i].pipe = it->second[i][6]; e->ops[i].planar = it->second[i][7]; e->ops[i].fused = it->second[i][8]; e->ops[i].fused_pw = it->second[i][9]; e->ops[i].fused_bf = it->second[i].size() > 10 ? it->second[i][10] : 0; }
     e->launches.assign(e->ops.size(), Launch());
     for (size_t i = 0; i < e->ops.size(); ++i) {
         int rc = prepare_op(e, i);
@@ -818,6 +831,22 @@ static int prepare_op(lp_engine* e, size_t idx) {
         fa.fz_c1 = e->tensors[stem.dst].cs;
         F.pipe = PIPE_FUSED2 + 1;
     }
+    if (op.fused_bf) {                  // BiFusion: transposed conv + cv1 + this cv3 as one kernel (this op's arguments + the other two ops' operands)
+        const Op& up = e->ops[op.bf_up];
+        const Op& c1 = e->ops[op.bf_cv1];
+        Launch& F = e->bf_fused[(int)idx];
+        F = L;
+        ConvArgs& fa = F.a;
+        fa.src[0].ptr = tptr(up.src[0]); fa.src[0].cs = e->tensors[up.src[0]].cs;
+        fa.src[1].ptr = tptr(c1.src[0]); fa.src[1].cs = e->tensors[c1.src[0]].cs;
+        fa.fz_w1 = e->dev_w + c1.w_off;
+        fa.fz_b1 = (const float*)(e->dev_w + c1.b_off);
+        fa.fz_act1 = c1.act;
+        fa.bf_wd = e->dev_w + up.w_off;
+        fa.bf_bd = (const float*)(e->dev_w + up.b_off);
+        fa.bf_wd_phase_stride = up.w_phase_stride;
+        F.pipe = PIPE_FUSED_BF + 1;
+    }
     if (op.fused_pw) {                  // the 1x1 layer before this one + this layer as one kernel
         const Op& pw = e->ops[idx - 1];
         Launch& F = e->pw_fused[(int)idx];
@@ -889,6 +918,41 @@ static bool pw_fused_possible(const lp_engine* e, size_t i) {
     }
     return true;
 }
+// BiFusion (common.py:504-527) at 64 channels: cv3 = 1x1 ReLU over [u, a, d] where u is the output of a transposed conv (no activation) of a
+// 64-channel coarse map and a the output of a 1x1 ReLU layer of a 128-channel map, u and a read by nobody else, every packing with 64-row cout
+// tiles.  Fills the indices of the two carried ops.  (With execution lanes on, a carried op still waits for its producers and records its event
+// on its lane -- it only launches nothing -- so the fused op's dependencies on the two carried ops order it behind THEIR inputs.)
+static bool bifusion_fused_possible(const lp_engine* e, size_t i, int* up, int* cv1) {
+    if (e->dtype == LP_F32 || i >= e->ops.size()) return false;
+    const Op& c = e->ops[i];
+    if (c.kind != OP_CONV || c.ksize != 1 || c.stride != 1 || c.nsrc != 3 || c.res >= 0 || c.dst2 >= 0 || c.mode != MODE_ACT || c.nct != 1 || c.nphase != 1 ||
+        c.nchunks != 3 || c.act != LP_ACT_RELU || conv_shape(e->dtype, c.cfg, 1, 1).CB != 64 || e->tensors[c.dst].cs != 64) return false;
+    int ju = -1, ja = -1;
+    for (size_t k = 0; k < i; ++k) {
+        if (e->ops[k].kind == OP_DECONV && e->ops[k].dst == c.src[0]) ju = (int)k;
+        if (e->ops[k].kind == OP_CONV && e->ops[k].dst == c.src[1]) ja = (int)k;
+    }
+    if (ju < 0 || ja < 0) return false;
+    const Op& u = e->ops[ju];
+    const Op& p = e->ops[ja];
+    if (u.nsrc != 1 || u.nct != 1 || u.nphase != 4 || u.nchunks != 1 || u.act != LP_ACT_NONE ||
+        conv_shape(e->dtype, u.cfg, 1, 1).CB != 64 || e->tensors[u.src[0]].cs != 64 || e->tensors[u.dst].cs != 64) return false;
+    if (p.ksize != 1 || p.stride != 1 || p.nsrc != 1 || p.res >= 0 || p.dst2 >= 0 || p.mode != MODE_ACT || p.nct != 1 || p.nphase != 1 || p.nchunks != 2 ||
+        p.act != LP_ACT_RELU || conv_shape(e->dtype, p.cfg, 1, 1).CB != 64 || e->tensors[p.src[0]].cs != 128 ||
+        e->tensors[p.dst].cs != 64 || e->tensors[c.src[2]].cs != 64) return false;
+    const Tensor& tf = e->tensors[c.dst];
+    const Tensor& tc = e->tensors[u.src[0]];
+    if (tf.h != 2 * tc.h || tf.w != 2 * tc.w) return false;
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+        if (k == i) continue;
+        const Op& o = e->ops[k];
+        for (int q = 0; q < o.nsrc; ++q) if (o.src[q] == u.dst || o.src[q] == p.dst) return false;
+        if (o.res == u.dst || o.res == p.dst) return false;
+    }
+    if (up) *up = ju;
+    if (cv1) *cv1 = ja;
+    return true;
+}
 static bool stem2_fused_now(const lp_engine* e, const void* x, int x_dtype) { return e->ops.size() > 2 && e->ops[2].fused && frame_direct(e, x, x_dtype); }
 
 // Detections-only forward: where the head ops write instead of the prediction tensor.
@@ -948,6 +1012,8 @@ static int run_op(lp_engine* e, size_t idx, const void* x, int x_dtype, float* p
     }
     const Launch& L = e->launches[idx];
     if (idx + 1 < e->ops.size() && e->ops[idx + 1].fused_pw) return LP_OK;   // this 1x1 layer runs inside the fused kernel of the next op
+    if (op.bf_carrier >= 0 && e->ops[op.bf_carrier].fused_bf) return LP_OK;  // ... inside BiFusion's fused kernel (the cv3 op)
+    if (op.fused_bf) return conv_pipe_launch(dt, PIPE_FUSED_BF, e->bf_fused[(int)idx].a, st);
     if (op.fused_pw) return conv_pipe_launch(dt, PIPE_FUSED_PW, e->pw_fused[(int)idx].a, st);
     if (idx == 1 && stem2_fused_now(e, x, x_dtype)) return LP_OK;            // runs inside the fused kernel of op 2
     if (idx == 2 && stem2_fused_now(e, x, x_dtype)) {
@@ -1193,7 +1259,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
     if (rc) return rc;
     if (reps < 1) reps = 3;
     hipStream_t st = (hipStream_t)stream;
-    for (Op& op : e->ops) { op.planar = 0; op.fused = 0; op.fused_pw = 0; }   // every op runs on its own while it is tuned
+    for (Op& op : e->ops) { op.planar = 0; op.fused = 0; op.fused_pw = 0; op.fused_bf = 0; }   // every op runs on its own while it is tuned
     rc = forward_single_lane(e, x, x_dtype, pred, st);
     if (rc) return rc;
     struct EventPair {      // destroyed on every return path
@@ -1408,9 +1474,35 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
             rc = prepare_op(e, i);
             if (rc) return rc;
         }
+        // BiFusion's transposed conv + cv1 + this cv3 as one kernel: against the three ops as tuned
+        if (op.bf_up >= 0 && !getenv("LP_NO_FUSED_BF")) {
+            auto time_set = [&](bool fused_form) -> float {
+                float ms_min = -1.f;
+                for (int round = 0; round < 3 && trc == LP_OK; ++round) {
+                    float ms = 0.f;
+                    if (hipEventRecord(e0, st) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    for (int r = 0; r < reps; ++r) {
+                        if (!fused_form) { run_op(e, (size_t)op.bf_up, x, x_dtype, pred, st); run_op(e, (size_t)op.bf_cv1, x, x_dtype, pred, st); }
+                        run_op(e, i, x, x_dtype, pred, st);
+                    }
+                    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { trc = LP_ERR_HIP; break; }
+                    if (ms_min < 0.f || ms < ms_min) ms_min = ms;
+                }
+                return ms_min;
+            };
+            op.fused_bf = 0;
+            const float t_sep = time_set(false);
+            op.fused_bf = 1;
+            float t_fused = -1.f;
+            if (prepare_op(e, i) == LP_OK && run_op(e, i, x, x_dtype, pred, st) == LP_OK) t_fused = time_set(true);
+            if (trc) return fail(trc, "autotune: event timing failed");
+            op.fused_bf = (t_sep >= 0.f && t_fused >= 0.f && t_fused < t_sep) ? 1 : 0;
+            rc = prepare_op(e, i);
+            if (rc) return rc;
+        }
     }
     std::vector<std::vector<int>> choice;
-    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar, op.fused, op.fused_pw});
+    for (const Op& op : e->ops) choice.push_back({op.cfg, op.nbuf, op.tile, op.stream_wc, op.stream_rd, op.rows, op.pipe, op.planar, op.fused, op.fused_pw, op.fused_bf});
     e->tuned[{e->B, e->H, e->W}] = choice;
     return LP_OK;
 }
@@ -1430,7 +1522,7 @@ extern "C" int lp_engine_copy_tuning(lp_engine* dst, const lp_engine* src) {
             for (size_t i = 0; i < dst->ops.size(); ++i) {
                 Op& op = dst->ops[i];
                 op.cfg = it->second[i][0]; op.nbuf = it->second[i][1]; op.tile = it->second[i][2];
-                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7]; op.fused = it->second[i][8]; op.fused_pw = it->second[i][9];
+                op.stream_wc = it->second[i][3]; op.stream_rd = it->second[i][4]; op.rows = it->second[i][5]; op.pipe = it->second[i][6]; op.planar = it->second[i][7]; op.fused = it->second[i][8]; op.fused_pw = it->second[i][9]; op.fused_bf = it->second[i].size() > 10 ? it->second[i][10] : 0;
                 int rc = prepare_op(dst, i);
                 if (rc) return rc;
             }
@@ -1452,6 +1544,14 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");
     const int ks = op.kind == OP_CONV ? op.ksize : 1, stv = op.kind == OP_CONV ? op.stride : 1;
     const int cb = conv_shape(e->dtype, op.cfg, ks, stv).CB;
+    if (cfg == LP_VARIANT_FUSED_BIFUSION) {       // BiFusion: transposed conv + cv1 + this cv3 as one kernel
+        if (op.bf_up < 0 || nbuf != 3) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: not the cv3 of a 64-channel BiFusion level");
+        op.fused_bf = 1;
+        e->tuned.erase({e->B, e->H, e->W});
+        if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
+    op.fused_bf = 0;
     if (cfg == LP_VARIANT_FUSED_PW_S2) {          // the 1x1 layer before this 3x3 stride-2 layer + this layer as one kernel
         if (!pw_fused_possible(e, (size_t)op_idx) || nbuf != 3)
             return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: no 1x1 layer of at most 64 channels feeds this 3x3 stride-2 layer alone");
@@ -1505,9 +1605,26 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
     return LP_OK;
 }
 
+extern "C" int lp_engine_op_carrier(const lp_engine* e, int op, int frame_direct_) {
+    if (!e || op < 0 || op >= (int)e->ops.size()) return -1;
+    const Op& o = e->ops[(size_t)op];
+    if (o.bf_carrier >= 0 && e->ops[(size_t)o.bf_carrier].fused_bf) return o.bf_carrier;
+    if ((size_t)op + 1 < e->ops.size() && e->ops[(size_t)op + 1].fused_pw) return op + 1;
+    if (frame_direct_ && e->ops.size() > 2 && e->ops[0].kind == OP_INPUT && e->ops[0].s2d) {
+        if (e->ops[2].fused && op <= 1) return 2;
+        if (e->ops[1].planar && op == 0) return 1;
+    }
+    return -1;
+}
+
 extern "C" int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf) {
     if (!e || op < 0 || op >= (int)e->ops.size()) return fail(LP_ERR_ARG, "lp_engine_op_variant: op index");
     const bool stream = e->ops[op].stream_wc != 0;
+    if (e->ops[op].fused_bf) {
+        if (cfg) *cfg = LP_VARIANT_FUSED_BIFUSION;
+        if (nbuf) *nbuf = 3;
+        return LP_OK;
+    }
     if (e->ops[op].fused_pw) {
         if (cfg) *cfg = LP_VARIANT_FUSED_PW_S2;
         if (nbuf) *nbuf = 3;

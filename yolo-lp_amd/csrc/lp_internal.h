@@ -47,6 +47,7 @@ enum ConvCfg { CFG_A = 0 /*128 couts x 128 px*/, CFG_B = 1 /*64 x 256*/, CFG_C =
 enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIPE_F = 2 /*128 x 128*/, PIPE_C = 3 /*32 x 512*/, PIPE_P = 4 /*the stem reading the NCHW frame: lp_stem_planar.inc*/, PIPE_COUNT = 5,
                  PIPE_FUSED2 = 5 /*stem + ERBlock_2[0] in one kernel: lp_stem2_fused.inc (not a variant of one layer)*/,
                  PIPE_FUSED_PW = 6 /*1x1 + 3x3 stride 2 in one kernel: lp_pw_s2_fused.inc*/,
+                 PIPE_FUSED_BF = 13 /*BiFusion's cv3(cat[upsample(x0), cv1(x1), d]) in one kernel: lp_bifusion_fused.inc*/,
                  PIPE16_D = 7, PIPE16_F = 9 /*D / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
                                                             chosen per layer by rule, never by timing*/,
                  PIPE16_V0 = 10, PIPE16_V1 = 11 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
@@ -102,6 +103,10 @@ struct ConvArgs {
     const void* fz_w1;
     const float* fz_b1;
     int fz_act1, fz_c1;
+    // bifusion_fused_kernel (lp_bifusion_fused.inc): src[0..2] = x0 (coarse map), x1, d; fz_w1 / fz_b1 = cv1's operands; the transposed conv's:
+    const void* bf_wd;
+    const float* bf_bd;
+    long long bf_wd_phase_stride;   // elements
     // MODE_DECODE
     int reg_bins;
     const float* proj;

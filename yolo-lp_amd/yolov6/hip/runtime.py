@@ -607,28 +607,20 @@ class Engine:
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
-                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 39: 'Md', 41: 'Mf', 42: 'V0', 43: 'V1'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
+                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 45: 'Fb', 39: 'Md', 41: 'Mf', 42: 'V0', 43: 'V1'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
         # Ops that launch nothing because a fused kernel carries them (the input op and the stem inside stem2_fused_kernel or behind
         # stem_planar_kernel, the 1x1 layer inside pw_s2_fused_kernel) are folded into their carrier's row: their FLOPs and bytes
         # are work of that kernel, and their own row keeps only the note (an empty event pair -- 1.4 us -- is not a 4 000 TFLOP/s launch).
         direct = x.dtype == self.dtype
         for o in ops:
             o['flops_own'], o['bytes_own'] = o['flops'], o['bytes']     # (the layer's own algorithmic figures: what bench.py's roofline sums)
-        for i, o in enumerate(ops):
-            carried = []
-            if o['variant'].startswith('Fz') and direct and i >= 2:
-                carried = [0, 1]
-            elif o['variant'].startswith('Fp') and i >= 1:
-                carried = [i - 1]
-            elif o['variant'].startswith('Pp') and direct and i == 1:
-                carried = [0]
-            for j in carried:
-                c = ops[j]
-                if c.get('carried_by') is not None:
-                    continue
-                o['flops'] += c['flops']
-                # the tensor between the two layers never reaches memory: the carrier's bytes are its own input-side and output-side ones
-                c.update(flops=0.0, bytes=0.0, ms=0.0, carried_by=i, variant=c['variant'] + '>%d' % i)
+        for j, c in enumerate(ops):
+            i = self.lib.lp_engine_op_carrier(self.h, j, 1 if direct else 0)
+            if i < 0 or i == j:
+                continue
+            ops[i]['flops'] += c['flops']
+            # the tensor between the layers never reaches memory: the carrier's bytes are its own input-side and output-side ones
+            c.update(flops=0.0, bytes=0.0, ms=0.0, carried_by=i, variant=c['variant'] + '>%d' % i)
         return ops
 
 
