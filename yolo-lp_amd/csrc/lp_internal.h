@@ -8,6 +8,12 @@
 
 #include "../../include/lp_hip.h"
 
+// order of the first two chunks' DMA requests in the prologue of the pipelined 3x3 kernels: 0 = halo pieces of both chunks,
+// then the weights; 1 = weights first (same-box A/B: profiles/r04_experiments.txt item 8)
+#ifndef LP_PRO_ORDER
+#define LP_PRO_ORDER 0
+#endif
+
 namespace lp {
 
 typedef _Float16 f16;
