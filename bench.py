@@ -50,12 +50,14 @@ def parse():
     ap.add_argument('--single-lane', type=int, default=-1, help='1: every engine issues its kernels on ONE stream (no side lanes for '
                     'independent branches; the default); 0: up to three lanes per forward '
                     '(profiles/r03_inflight_lanes.txt, profiles/r03_round_ab.txt)')
-    ap.add_argument('--roofline-file', default=os.path.join(ROOT, 'profiles', 'r03_roofline.json'),
+    ap.add_argument('--roofline-file', default='',
                     help='roofline of the 3x3 layers from a rocprofv3 --kernel-trace of this command (tools/roofline_from_trace.py); '
-                         'reported as roofline.frac when its kernel-source hash equals that of this build')
-    ap.add_argument('--traffic-file', default=os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'),
+                         'reported as roofline.frac when its kernel-source hash equals that of this build '
+                         '(default: profiles/r04_roofline[_<model>_<size>_bs<batch>_<dtype>].json, the suffix for every workload but the default one)')
+    ap.add_argument('--traffic-file', default='',
                     help='per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run (tools/pmc_traffic.py); used only '
-                         'when the kernel-source hash recorded in it equals that of the sources this build was made from')
+                         'when the kernel-source hash recorded in it equals that of the sources this build was made from '
+                         '(default: profiles/r04_pmc_traffic[_<workload>].json)')
     ap.add_argument('--profile-inner', type=int, default=4, help='back-to-back launches of each op per event pair in the per-op '
                     'timing (amortises the cost of the event pair itself)')
     return ap.parse_args()
@@ -309,11 +311,16 @@ def main():
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         total_ms = sum(o['ms'] for o in ops)
         traffic, traffic_note = None, 'no PMC file for this workload'
+        tf_ok = rf_ok = None      # the profile files of this workload, when measured on this build's kernel sources
         default_workload = (args.model, args.batch, args.size, args.dtype) == ('yololps', 32, 640, 'f16')
-        if default_workload and os.path.exists(args.traffic_file):     # PMC counters come from a separate rocprofv3 pass
+        suffix = '' if default_workload else '_%s_%d_bs%d_%s' % (args.model, args.size, args.batch, args.dtype)
+        args.traffic_file = args.traffic_file or os.path.join(ROOT, 'profiles', 'r04_pmc_traffic%s.json' % suffix)
+        args.roofline_file = args.roofline_file or os.path.join(ROOT, 'profiles', 'r04_roofline%s.json' % suffix)
+        if os.path.exists(args.traffic_file):     # PMC counters come from a separate rocprofv3 pass
             from yolov6.hip.srchash import source_hash
             tf = json.load(open(args.traffic_file))
             if tf.get('kernel_source_hash') == source_hash():
+                tf_ok = tf
                 traffic, traffic_note = tf.get('hbm_bytes_per_launch'), os.path.relpath(args.traffic_file, ROOT)
             else:     # counters of another code state would go stale silently: report none
                 traffic_note = 'stale: %s was measured on kernel sources %s, this build is %s' % (
@@ -327,6 +334,7 @@ def main():
             'backbone_flops': bb_fl, 'backbone_dispatches': sum(1 for o in ops[:nbb] if o['ms'] * 1e3 >= 3.0),   # (ops carried by a fused kernel launch nothing)
             'timing': 'hipEvent pairs on the launch stream around %d back-to-back launches of each op' % max(1, args.profile_inner),
             'launches': len(conv3), 'avg_launch_ms': round(ms3 / max(1, len(conv3)), 4),
+            'conv3_layers': len(conv3), 'conv3_flops_per_step': fl3,
             'flops_per_launch': round(fl3 / max(1, len(conv3)) / 1e9, 3),
             'algorithmic_bytes_per_launch': round(sum(o['bytes_own'] for o in conv3) / max(1, len(conv3))),
             'all_mfma_kernels_tflops': round(sum(o['flops_own'] for o in allmm) / (sum(o['ms'] for o in allmm) * 1e-3) / 1e12, 2),
@@ -338,10 +346,11 @@ def main():
         # event-timed figure stays beside it as frac_event.
         roofline['frac_event'] = roofline['frac']
         roofline['frac_source'] = 'live hipEvent timing (no kernel-trace roofline file for this workload and build)'
-        if default_workload and os.path.exists(args.roofline_file):
+        if os.path.exists(args.roofline_file):
             from yolov6.hip.srchash import source_hash
             rf = json.load(open(args.roofline_file))
             if rf.get('kernel_source_hash') == source_hash():
+                rf_ok = rf
                 roofline['achieved_event'] = roofline['achieved']
                 roofline['achieved'], roofline['frac'] = rf['achieved_tflops'], rf['frac']
                 roofline['trace_us_per_step'] = rf['conv3_us_per_step']
@@ -366,7 +375,16 @@ def main():
                 'kernel': 'whole forward (%d launches; no single kernel dominates a bandwidth-bound configuration)' % len(ops),
                 'algorithmic_bytes_per_launch': round(alg), 'launches': 1, 'avg_launch_ms': round(total_ms, 4),
                 'throughput_hbm_frac': round(world * B * args.steps / elapsed * (mb_img * scale) * 1e6 / 8e12 / world, 4),
-                'mfma_3x3_tflops': round(ach, 2)})
+                'mfma_3x3_tflops': round(ach, 2), 'mfma_3x3_frac': roofline['frac']})
+            roofline['frac_event'] = roofline['frac']
+            if rf_ok is not None and rf_ok.get('forward_us_per_step'):      # the forward's kernels in the trace (one batch in flight)
+                gbs_t = alg / (rf_ok['forward_us_per_step'] * 1e-6) / 1e9
+                roofline.update({'achieved_event': roofline['achieved'], 'achieved': round(gbs_t, 1), 'frac': round(gbs_t / 8000.0, 4),
+                                 'trace_us_per_step': rf_ok['forward_us_per_step'],
+                                 'frac_source': 'algorithmic bytes of the forward / summed kernel-trace duration of its dispatches, %s (%d timed steps)'
+                                                % (os.path.relpath(args.roofline_file, ROOT), rf_ok['steps'])})
+            if tf_ok is not None and tf_ok.get('forward_hbm_bytes_per_step'):
+                roofline['traffic'] = tf_ok['forward_hbm_bytes_per_step']
         result = {
             'metric': METRIC, 'value': round(world * B * args.steps / elapsed, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

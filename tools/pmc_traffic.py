@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov6.hip.srchash import source_hash   # noqa: E402
 
 
+NMS = re.compile(r'score_kernel|sort_kernel|greedy_kernel|zero_counts|counts_kernel|nms_')
 CONV3 = re.compile(r'conv3x3_\w*kernel|stem_planar_kernel|stem2_fused_kernel|pw_s2_fused_kernel|conv_mfma_kernelI\w+?Li\dELi3E')
 
 
@@ -33,7 +34,10 @@ def step_values(d, counter, steps):
     ends = [i for i, r in enumerate(rows) if 'sort_kernel' in r['Kernel_Name']]
     per_step = sum(1 for r in rows[ends[-2] + 1:ends[-1]] if CONV3.search(r['Kernel_Name']))
     vals = [float(r['Counter_Value']) for r in rows[:ends[-1]] if CONV3.search(r['Kernel_Name'])]
-    return vals[-per_step * steps:], per_step
+    # every forward kernel of the last `steps` steps (all but the NMS's): the whole-forward traffic of a bandwidth-bound configuration
+    first = ends[-1 - steps] + 1
+    fwd = [float(r['Counter_Value']) for r in rows[first:ends[-1]] if not NMS.search(r['Kernel_Name'])]
+    return vals[-per_step * steps:], per_step, sum(fwd) / steps
 
 
 ap = argparse.ArgumentParser()
@@ -43,13 +47,15 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--bench', required=True, help='a JSON line of bench.py on this build: the number of 3x3 layers per step (the per-launch '
                 'figures are per LAYER, like bench.py roofline; a fused kernel runs two)')
 a = ap.parse_args()
-layers = json.loads([l for l in open(a.bench).read().splitlines() if l.startswith('{')][-1])['roofline']['launches']
-fetch, per_step = step_values(a.fetch_dir, 'FETCH_SIZE', a.steps)
-write, _ = step_values(a.write_dir, 'WRITE_SIZE', a.steps)
+rl = json.loads([l for l in open(a.bench).read().splitlines() if l.startswith('{')][-1])['roofline']
+layers = rl.get('conv3_layers') or rl['launches']
+fetch, per_step, fwd_fetch = step_values(a.fetch_dir, 'FETCH_SIZE', a.steps)
+write, _, fwd_write = step_values(a.write_dir, 'WRITE_SIZE', a.steps)
 fetch_b = sum(fetch) / (a.steps * layers) * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
 write_b = sum(write) / (a.steps * layers) * 1024
 print(json.dumps({'kernel': '3x3 conv layers (conv3x3_pipe_kernel + stem2_fused_kernel / stem_planar_kernel + conv_mfma_kernel<KS=3>), bytes per LAYER', 'kernel_source_hash': source_hash(),
                   'dispatches_averaged': len(fetch), 'dispatches_per_step': per_step, 'layers_per_step': layers,
                   'fetch_bytes_per_launch': round(fetch_b), 'write_bytes_per_launch': round(write_b),
                   'hbm_bytes_per_launch': round(fetch_b + write_b),
+                  'forward_hbm_bytes_per_step': round(fwd_fetch * 1024 * 2 + fwd_write * 1024),
                   'correction': 'FETCH_SIZE KiB x1024 x2 (gfx950 wide reads), WRITE_SIZE KiB x1024'}))

@@ -33,7 +33,8 @@ def main():
     a = ap.parse_args()
     d = json.loads([l for l in open(a.bench_json).read().splitlines() if l.startswith('{')][-1])
     r = d['roofline']
-    flops_step = r['flops_per_launch'] * 1e9 * r['launches']
+    flops_step = r.get('conv3_flops_per_step') or r['flops_per_launch'] * 1e9 * r['launches']
+    layers = r.get('conv3_layers') or r['launches']
     rows = []
     for f in glob.glob(a.trace_dir + '/**/*kernel_trace.csv', recursive=True):
         rows += [(int(x['Start_Timestamp']), int(x['End_Timestamp']), x['Kernel_Name']) for x in csv.DictReader(open(f))]
@@ -55,6 +56,8 @@ def main():
             us_bb = sum(sum(fwd[k * per:k * per + r['backbone_dispatches']]) for k in range(a.steps)) / a.steps
             bb = {'backbone_us_per_step': round(us_bb, 1), 'backbone_dispatches': r['backbone_dispatches'], 'forward_dispatches_per_step': per,
                   'backbone_frac': round(r['backbone_flops'] / (us_bb * 1e-6) / 1e12 / a.peak, 4)}
+    # the whole forward (every kernel of a step but the NMS's): the denominator of a bandwidth-bound configuration's roofline
+    fwd_us = sum((e_ - s_) / 1e3 for s_, e_, n in seg if not NMS.search(n)) / a.steps
     per_step = len(tail) / a.steps
     us_step = sum(tail) / a.steps
     ach = flops_step / (us_step * 1e-6) / 1e12
@@ -62,7 +65,7 @@ def main():
         'kernel_source_hash': source_hash(), 'workload': d['config']['workload'],
         'kernel': '3x3 convolution layers: every dispatch of conv3x3_*kernel / stem2_fused_kernel / stem_planar_kernel / pw_s2_fused_kernel / '
                   'conv_mfma_kernel<KS=3> in the timed steps of a rocprofv3 --kernel-trace of bench.py --inflight 1',
-        'steps': a.steps, 'dispatches_per_step': round(per_step, 2), 'layers_per_step': r['launches'],
+        'steps': a.steps, 'dispatches_per_step': round(per_step, 2), 'layers_per_step': layers, 'forward_us_per_step': round(fwd_us, 1),
         'conv3_us_per_step': round(us_step, 1), 'avg_dispatch_us': round(sum(tail) / len(tail), 2),
         'flops_per_step': flops_step, 'achieved_tflops': round(ach, 1), 'peak_tflops': a.peak, 'frac': round(ach / a.peak, 4),
         'bench_event_timed_frac': r.get('frac_event', r['frac']), 'bench_value_inflight1': d.get('value_inflight1'), **(bb or {})}))
