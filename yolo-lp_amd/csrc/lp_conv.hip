@@ -333,6 +333,11 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
         return fail(LP_ERR_ARG, "conv3x3 pipe: tile does not fit the kernel configuration");
     if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv3x3 pipe: tiles do not cover the output");
     if (pipe_is_16v(pcfg) && (a.nct * s.CB > 512 || a.chunk_begin[a.nsrc] > 32)) return fail(LP_ERR_ARG, "conv3x3 pipe16v: layer exceeds the kernel's LDS tables");
+    if (pipe_is_16v(pcfg)) {      // its epilogue addresses a tile's rows with 32-bit element offsets from the tile origin
+        int stride = a.out_pix_stride > a.res_cs ? a.out_pix_stride : a.res_cs;
+        if (a.out2 && a.out2_pix_stride > stride) stride = a.out2_pix_stride;
+        if (((long long)a.TH * a.Wo + a.TW) * stride + 2048 >= (1ll << 31)) return fail(LP_ERR_ARG, "conv3x3 pipe16v: a tile's rows span more than 2^31 elements");
+    }
     if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nct * s.CB > 1024 || a.nphase != 1 || a.out_scale != 1 || a.Ho != a.H || a.Wo != a.W)
         return fail(LP_ERR_ARG, "conv3x3 pipe: not a 3x3 stride-1 layer this kernel runs");
     switch (dtype) {
