@@ -192,8 +192,54 @@ def test_roofline_from_trace_arithmetic(tmp_path):
     # the backbone fraction: the first two of the five forward kernels of each timed step (80 + 60 us), NMS kernels not counted
     assert r['forward_dispatches_per_step'] == 5 and abs(r['backbone_us_per_step'] - 140.0) < 1e-6
     assert abs(r['backbone_frac'] - 70e9 / 140e-6 / 1e12 / 2500.0) < 1e-3
+    # the whole forward of a step (the denominator of a bandwidth-bound configuration's roofline): all five kernels, not the NMS's
+    assert abs(r['forward_us_per_step'] - 205.0) < 1e-6
     from yolov6.hip.srchash import source_hash
     assert r['kernel_source_hash'] == source_hash()
     idle = subprocess.run([sys.executable, os.path.join(root, 'tools', 'micro', 'fwd_idle.py'), str(d), str(steps)],
                           capture_output=True, text=True, check=True).stdout
     assert 'idle 2.0 us' in idle and 'idle before lp::sort_kernel' in idle, idle
+
+
+def test_pmc_traffic_arithmetic(tmp_path):
+    """tools/pmc_traffic.py (roofline.traffic): two synthetic rocprofv3 --pmc passes with known counter values.  The per-layer figure
+    takes the 3x3 dispatches of the last `steps` steps only (mangled names of fp16 AND bf16 instantiations: rocprofv3's demangler garbles
+    the latter, the profile runs use -M), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; the whole-forward figure
+    takes every kernel of those steps but the NMS's."""
+    import json
+    import subprocess
+    import sys
+    steps, warm = 3, 2
+
+    def write(d, counter, scale):
+        d.mkdir()
+        rows = []
+
+        def k(name, val):
+            rows.append((len(rows) + 1, name, counter, val))
+
+        def step(f):
+            k('_ZN2lp22conv3x3_pipe16v_kernelIDF16bLi10ELb0EEEvNS_8ConvArgsEi.kd', 1000 * f)         # bf16 instantiation, mangled
+            k('_ZN2lp16conv_mfma_kernelIDF16_Li3ELi3ELi2ELi0ELi2EEEvNS_8ConvArgsE.kd', 500 * f)       # 3x3 stride 2
+            k('_ZN2lp16conv_mfma_kernelIDF16bLi5ELi1ELi1ELi0ELi2EEEvNS_8ConvArgsE.kd', 200 * f)       # a 1x1 layer: forward, not 3x3
+            k('_ZN2lp12score_kernelEPKfiiPyPi.kd', 7000)                                               # NMS: in neither figure
+            k('_ZN2lp11sort_kernelEPyPKii.kd', 9000)
+        for _ in range(warm):
+            step(10 * scale)
+        for _ in range(steps):
+            step(scale)
+        with open(d / 'p_counter_collection.csv', 'w') as f:
+            f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for r in rows:
+                f.write('%d,"%s","%s",%s\n' % r)
+    write(tmp_path / 'fetch', 'FETCH_SIZE', 1.0)
+    write(tmp_path / 'write', 'WRITE_SIZE', 0.5)
+    (tmp_path / 'bench.json').write_text(json.dumps({'roofline': {'launches': 1, 'conv3_layers': 2}}) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pmc_traffic.py'), str(tmp_path / 'fetch'), str(tmp_path / 'write'),
+                          '--steps', str(steps), '--bench', str(tmp_path / 'bench.json')], capture_output=True, text=True, check=True).stdout
+    r = json.loads(out)
+    assert r['dispatches_per_step'] == 2 and r['layers_per_step'] == 2 and r['dispatches_averaged'] == 2 * steps
+    assert r['fetch_bytes_per_launch'] == round(1500 / 2 * 1024 * 2) and r['write_bytes_per_launch'] == round(750 / 2 * 1024)
+    assert r['hbm_bytes_per_launch'] == r['fetch_bytes_per_launch'] + r['write_bytes_per_launch']
+    assert r['forward_hbm_bytes_per_step'] == round(1700 * 1024 * 2 + 850 * 1024)
