@@ -202,6 +202,11 @@ enum { LP_VARIANT_STREAM64 = 16, LP_VARIANT_STREAM128 = 17, LP_VARIANT_ROWS = 18
  * Bit-identical to the three launches.  lp_engine_op_carrier: index of the op whose kernel currently carries `op` (fused stem, fused 1x1 + 3x3
  * stride 2, fused BiFusion; frame_direct != 0: the caller's frame has the engine's dtype), or -1: the op launches its own kernel. */
 enum { LP_VARIANT_FUSED_BIFUSION = 45 };
+/* LP_VARIANT_BOX_SPARSE (46, the default) / LP_VARIANT_BOX_DENSE (47): a head_box op in the detections-only forward (lp_engine_forward_det) computes
+ * reg_preds / cor_preds + dist2bbox / dist2cor (effidehead.py:262-301, general.py:29-66) for the anchors the level's class predictors let pass only,
+ * or for every anchor.  The candidate rows lp_nms_candidates reads are the same bits either way; the sparse form needs one execution lane and the
+ * op order cls(level), box(level) per level (else the dense form runs whatever is set).  nbuf is ignored. */
+enum { LP_VARIANT_BOX_SPARSE = 46, LP_VARIANT_BOX_DENSE = 47 };
 int lp_engine_op_carrier(const lp_engine* e, int op, int frame_direct);
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);
 int lp_engine_op_variant(const lp_engine* e, int op, int* cfg, int* nbuf);

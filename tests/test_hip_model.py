@@ -486,6 +486,71 @@ def test_detections_only_forward_matches_forward_plus_nms(name, kw, B, H, W, dty
         assert torch.equal(o, r)
 
 
+@pytest.mark.parametrize('name,kw,B,H,W,dtype', [
+    ('yololps', dict(sigma=0.25), 3, 640, 640, torch.float16),
+    ('yololpn', dict(sigma=0.6), 2, 320, 416, torch.float16),
+    ('yololps', dict(width=0.125, sigma=1.5), 2, 256, 192, torch.bfloat16),
+], ids=['lps-full', 'lpn', 'lps-tiny-bf16'])
+def test_box_predictors_for_candidates_only_write_the_same_rows(name, kw, B, H, W, dtype):
+    """LP_VARIANT_BOX_SPARSE (default) against LP_VARIANT_BOX_DENSE: in the detections-only forward the box predictors of a level run
+    for the anchors its class predictors let pass only.  Columns 0..11 of every candidate's row are the dense form's bits, rows of
+    anchors that did not pass are not written at all (the workspace is poisoned first), and detections are identical -- at the
+    inference threshold, at the evaluation threshold (nearly every anchor passes) and at one nothing passes."""
+    from yolov6.hip import runtime, abi
+    from yolov6.utils.synth import build_synthetic
+    m = build_synthetic(CFG(name), **kw).cuda().to(dtype)
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(5)).cuda().to(dtype)
+    eng = runtime.engine_for(m)
+    eng.autotune = False
+    with torch.no_grad():
+        eng.forward(x)                                            # binds the arena (op descriptions exist from then on)
+    boxes = [i for i, k in enumerate(eng.op_kinds()) if k == 'head_box']
+    assert len(boxes) == 3
+    for conf in (0.4, 0.03, 1.0):
+        got = {}
+        for mode in (abi.LP_VARIANT_BOX_DENSE, abi.LP_VARIANT_BOX_SPARSE):
+            for op in boxes:
+                eng.set_variant(op, mode, 1)
+            ws = eng.det_workspace(B, H, W)
+            ws.fill_(0xFF)                                       # NaN rows: what the kernels do not write stays recognisable
+            _, _, N = eng.forward_det(x, conf, ws=ws)
+            torch.cuda.synchronize()
+            # the workspace as lp_nms.hip carves it (256-byte aligned pieces): counts [B], keys [B][NP], candidate rows [B][N][28], ...
+            off = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+            cnt = ws[off:][:4 * B].view(torch.int32).clone()
+            NP = 1 << max(6, (N - 1).bit_length())
+            keys_off = off + (4 * B + 255) // 256 * 256
+            keys = ws[keys_off:][:8 * B * NP].view(torch.int64).view(B, NP).clone()
+            rows_off = keys_off + (8 * B * NP + 255) // 256 * 256
+            rows = ws[rows_off:][:4 * B * N * 28].view(torch.float32).view(B, N, 28).clone()
+            det = runtime.nms_candidates((ws, B, N), 0.45, 300, want_keep=True)
+            torch.cuda.synchronize()
+            got[mode] = (cnt, keys, rows, det)
+        (c0, k0, r0, d0), (c1, k1, r1, d1) = got[abi.LP_VARIANT_BOX_DENSE], got[abi.LP_VARIANT_BOX_SPARSE]
+        assert torch.equal(c0, c1)
+        written = 0
+        for b in range(B):
+            n = int(c0[b])
+            a0 = (k0[b, :n] & 0xFFFFFFFF).sort().values
+            a1 = (k1[b, :n] & 0xFFFFFFFF).sort().values
+            assert torch.equal(a0, a1)                           # the same anchors pass (their order in the lists is arbitrary)
+            assert torch.equal(r0[b, a0, :12].view(torch.int32), r1[b, a0, :12].view(torch.int32))
+            assert not torch.isnan(r1[b, a0, :12]).any()
+            mask = torch.ones(N, dtype=torch.bool, device=r1.device)
+            mask[a0] = False
+            assert torch.isnan(r1[b, mask, :12]).all()           # no row of an anchor that did not pass is touched
+            assert not torch.isnan(r0[b, :, :12]).any()          # (the dense form writes them all)
+            written += n
+        if conf == 0.03:
+            assert written > B * N // 2
+        if conf == 1.0:
+            assert written == 0
+        for t0, t1 in zip(d0, d1):                                # detections, counts, kept anchors
+            assert torch.equal(t0, t1)
+    for op in boxes:
+        eng.set_variant(op, abi.LP_VARIANT_BOX_SPARSE, 1)
+
+
 def test_nms_rejects_bad_arguments():
     from yolov6.utils.nms import non_max_suppression
     from yolov6.hip.runtime import nms_padded

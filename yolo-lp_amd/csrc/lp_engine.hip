@@ -50,6 +50,7 @@ struct Op {
     int stream_wc = 0, stream_rd = 2;   // stream_wc != 0: the streaming 1x1 kernel (2 or 4 cout tiles per wave) runs this op
     int rows = 0;                       // OP_HEAD_CLS: the row-writer kernel (lp_head_rows.inc) runs this op
     size_t det_scratch = (size_t)-1;    // OP_HEAD_CLS whose detections-only form needs a prediction scratch: its arena offset (after bind)
+    int box_sparse = 1;                 // OP_HEAD_BOX, detections-only forward: boxes of the level's candidates only (LP_VARIANT_BOX_SPARSE / _DENSE)
     int pipe = 0;                       // != 0: the pipelined 3x3 stride-1 kernel (lp_conv3x3_pipe.inc), configuration pipe - 1
     int fused_pw = 0;                   // 3x3 stride-2 layer behind a 1x1 layer (BiFusion's downsample(cv2(x))): != 0: the two run as ONE kernel
                                         // (lp_pw_s2_fused.inc; fused_pw - 1 = its tile choice); the 1x1 op before it is then skipped
@@ -106,6 +107,11 @@ struct lp_engine {
     bool single_lane = true;          // lp_engine_set_single_lane (default): every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
     bool mfma16 = getenv("LP_NO_MFMA16") == nullptr;   // lp_engine_set_mfma16: eligible 3x3 layers run on the 16x16x32 family (op_fam16)
+    // Detections-only forward: the box predictors of a level may run for the level's CANDIDATES only (head_box_det_kernel, sparse form) when,
+    // in op order, exactly the class predictors of the same level sit between a box op and the box op before it -- then the entries
+    // appended to the key lists between the two are this level's.  box_ord[i] = ordinal of box op i among the box ops (-1: not one).
+    bool box_sparse_ok = false;
+    std::vector<int> box_ord;
     struct CachedGraph {               // one captured forward; valid for exactly these pointers / dtype / tuning state
         hipGraphExec_t exec = nullptr;
         const void* x = nullptr;
@@ -520,6 +526,21 @@ extern "C" int lp_engine_finalize(lp_engine* e, int n_levels) {
         e->ops[i].bf_up = up;
         e->ops[i].bf_cv1 = c1;
         e->ops[(size_t)up].bf_carrier = e->ops[(size_t)c1].bf_carrier = (int)i;
+    }
+    {   // whether the op order allows the sparse box kernel (see lp_engine::box_sparse_ok)
+        e->box_ord.assign(e->ops.size(), -1);
+        bool ok = true;
+        int nbox = 0, cls_seen = 0, cls_level = -1;
+        for (size_t i = 0; i < e->ops.size(); ++i) {
+            const Op& o = e->ops[i];
+            if (o.kind == OP_HEAD_CLS) { ++cls_seen; cls_level = o.level; }
+            if (o.kind == OP_HEAD_BOX) {
+                ok = ok && cls_seen == 1 && cls_level == o.level;
+                e->box_ord[i] = nbox++;
+                cls_seen = 0;
+            }
+        }
+        e->box_sparse_ok = ok && nbox >= 1 && nbox <= 4 && cls_seen == 0;
     }
     e->finalized = true;
     return LP_OK;
@@ -973,7 +994,22 @@ static int run_head_det(lp_engine* e, size_t idx, const DetCtx& dc, hipStream_t 
         a.out_pix_stride = LP_DET_COLS;
         a.out_img_stride = (long long)N * LP_DET_COLS;
         static const bool no_box_stream = getenv("LP_NO_BOX_STREAM") != nullptr;     // (A/B switch: the generic decode kernel)
-        if (!no_box_stream && head_box_det_fits(a, L.cb_pack, L.ks, L.st)) return head_box_det_launch(dt, a, L.cb_pack, st);
+        static const bool no_box_sparse = getenv("LP_NO_BOX_SPARSE") != nullptr;     // (A/B switch: boxes of every anchor)
+        if (!no_box_stream && head_box_det_fits(a, L.cb_pack, L.ks, L.st)) {
+            // one lane: the class kernel of this level has appended its candidates in front of this launch, nobody else in between
+            if (!no_box_sparse && op.box_sparse && e->box_sparse_ok && (e->n_lanes <= 1 || e->single_lane) && e->box_ord[idx] >= 0 && N >= 8) {
+                const int k = e->box_ord[idx];
+                int* const snaps = dc.w.kept;           // [4][B] ints of the NMS's `kept` array, which lp_nms_candidates only writes later
+                a.det_keys = dc.w.keys;
+                a.det_cnt = dc.w.cnt;
+                a.det_np = dc.w.NP;
+                a.det_n = N;
+                a.det_anchor0 = anchor0;
+                a.det_prev = k > 0 ? snaps + (size_t)(k - 1) * e->B : nullptr;
+                a.det_snap = snaps + (size_t)k * e->B;
+            }
+            return head_box_det_launch(dt, a, L.cb_pack, st);
+        }
         return conv_launch(dt, L.cfg, L.mode, L.ks, L.st, L.nbuf, a, st);
     }
     if (op.det_scratch == (size_t)-1) {     // class predictors + candidate selection in one kernel
@@ -1539,6 +1575,12 @@ extern "C" int lp_engine_set_op_variant(lp_engine* e, int op_idx, int cfg, int n
         op.rows = cfg == LP_VARIANT_ROWS;
         e->tuned.erase({e->B, e->H, e->W});
         if (e->arena && op_idx < (int)e->launches.size()) return prepare_op(e, (size_t)op_idx);
+        return LP_OK;
+    }
+    if (op.kind == OP_HEAD_BOX && (cfg == LP_VARIANT_BOX_SPARSE || cfg == LP_VARIANT_BOX_DENSE)) {
+        // detections-only forward: boxes of the level's candidates only / of every anchor (same rows for the candidates; no tuning state involved)
+        op.box_sparse = cfg == LP_VARIANT_BOX_SPARSE;
+        ++e->epoch;      // (captured graphs hold the launch)
         return LP_OK;
     }
     if (op.kind == OP_INPUT || op.kind == OP_POOL || op.mode != MODE_ACT) return fail(LP_ERR_UNSUPPORTED, "lp_engine_set_op_variant: op has no variants");

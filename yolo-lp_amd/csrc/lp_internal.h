@@ -105,6 +105,10 @@ struct ConvArgs {
     int* det_cnt;
     int det_np, det_n, det_anchor0;   // keys per image (power of two), anchors per image, first anchor of this level
     float det_conf;
+    //   head_box_det_kernel, sparse form (det_keys set on a MODE_DECODE launch): boxes of the level's candidates only; det_prev [B] = where
+    //   the level's entries begin in the key lists (null: 0), det_snap [B] = where they end (written for the next level)
+    const int* det_prev;
+    int* det_snap;
     // stem2_fused_kernel (lp_stem2_fused.inc): the stem's packed weights, bias, activation and stored channels (src[0] = the frame)
     const void* fz_w1;
     const float* fz_b1;

@@ -584,6 +584,18 @@ class Engine:
         if pr is not None and pr[1].query():
             self.pass_rate = float(pr[0].float().mean()) / max(1, pr[2])
 
+    def op_kinds(self):
+        """Kind name of every op of the frozen graph, in op order ('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box'); needs a
+        bound arena (``bind`` / a forward)."""
+        out = []
+        for i in range(self.lib.lp_engine_num_ops(self.h)):
+            kind, ks, cin, cout = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            abi.check(self.lib.lp_engine_op_info(self.h, i, ctypes.byref(kind), ctypes.byref(ks), ctypes.byref(cin),
+                                                 ctypes.byref(cout), ctypes.byref(fl), ctypes.byref(by)), 'lp_engine_op_info')
+            out.append(('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value])
+        return out
+
     def profile(self, x, reps=3, inner=1):
         """Per-op device milliseconds (hipEvent pairs around ``inner`` back-to-back launches of each op) + op descriptions,
         for bench.py."""
