@@ -298,7 +298,7 @@ def main():
         # the backbone alone (north_star's ">= 70 % MFMA roofline on the conv backbone"): all its ops, SURVEY 8(d)'s algorithmic FLOPs
         nbb = getattr(eng, 'backbone_ops', 0)
         bb_fl, bb_ms = sum(o['flops_own'] for o in ops[:nbb]), sum(o['ms'] for o in ops[:nbb])
-        KNAME = {'P': 'conv3x3_pipe_kernel', 'M': 'conv3x3_pipe16_kernel', 'V': 'conv3x3_pipe16v_kernel', 'Fz': 'stem2_fused_kernel (stem + the layer behind it)',
+        KNAME = {'P': 'conv3x3_pipe_kernel', 'M': 'conv3x3_pipe16_kernel', 'V': 'conv3x3_pipe16v_kernel', 'X': 'conv3x3_s2p16_kernel', 'Fz': 'stem2_fused_kernel (stem + the layer behind it)',
                  'Fp': 'pw_s2_fused_kernel (1x1 + 3x3 stride 2)', 'Pp': 'stem_planar_kernel'}
         names = {}
         for o in conv3:

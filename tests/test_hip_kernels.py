@@ -611,6 +611,66 @@ def test_conv3x3_pipe16(case, dtype):
     assert base16 is not None
 
 
+S2P16_CASES = [
+    # (cin list, cout, act, h, w of the INPUT map, B): 3x3 stride-2 layers with the 128-row weight packing (more than 64 stored couts)
+    ([64], 128, 'relu', 160, 160, 3),               # yololps' ERBlock_3[0]: 5 x 40 tiles, several per workgroup
+    ([128], 256, 'relu', 80, 80, 8),                # ERBlock_4[0]: two cout tiles
+    ([256], 512, 'silu', 40, 40, 6),                # ERBlock_5[0]: sixteen chunks, four cout tiles, 10 x 20 tiles
+    ([48], 96, 'relu', 64, 96, 2),                  # yolov6m's ERBlock_2[0]: three chunks (odd: tiles alternate ring phases), partial cout tile
+    ([96], 200, 'none', 34, 22, 3),                 # ragged 17 x 11 output, partial second cout tile (192 couts would take the 64-row packing)
+    ([16], 128, 'relu', 252, 124, 7),               # ONE chunk per tile, >= 3 tiles per workgroup: the ring crosses a tile at every chunk
+    ([64, 64], 128, 'relu', 40, 40, 5),             # two sources
+    ([128], 72, 'relu', 26, 54, 5),                 # partial cout tile
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('case', S2P16_CASES, ids=lambda c: '%s-%d-%s-%dx%dx%d' % ('+'.join(map(str, c[0])), c[1], c[2], c[5], c[3], c[4]))
+def test_conv3x3_s2p16(case, dtype):
+    """The 3x3 stride-2 kernel on v_mfma_f32_16x16x32 (LP_VARIANT_PIPE16_S2A / _S2B, lp_conv3x3_s2p16.inc): within the stated
+    tolerance of F.conv2d in fp32 and of conv_mfma_kernel<KS=3,S=2> (another fp32 summation order, so not bit for bit), its two wave
+    grids bit-identical to each other, every launch reproducible with a poisoned LDS in front of it (two-slot ring, tiles with one,
+    three and sixteen chunks)."""
+    from yolov6.hip import abi
+    cins, cout, act, h, w, B = case
+    sl = 5 if h <= 64 else 3
+    eng = _engine(dtype)
+    eng.autotune = False
+    srcs = [eng.tensor(c, sl) for c in cins]
+    cin = sum(cins)
+    wt = _rand((cout, cin, 3, 3), 1, (2.0 / (cin * 9)) ** 0.5)
+    bias = _rand((cout,), 2, 0.5)
+    act_id = {'none': abi.LP_ACT_NONE, 'relu': abi.LP_ACT_RELU, 'silu': abi.LP_ACT_SILU}[act]
+    dst = eng.conv(srcs, wt, bias, 3, 2, act_id, sl)
+    eng.finish()
+    H, W = h << sl, w << sl
+    eng.bind(B, H, W)
+    xs = [_rand((B, c, h, w), 10 + i) for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()
+    for t, x in zip(srcs, xs):
+        _fill(eng, t, x)
+    op = eng.lib.lp_engine_num_ops(eng.h) - 1
+    _run(eng, B, H, W)
+    base32 = eng.tensor_view(dst).clone()                  # the default variant: conv_mfma_kernel<KS=3,S=2>
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), q(wt), bias, stride=2, padding=1)
+    ref = {'none': lambda t: t, 'relu': F.relu, 'silu': F.silu}[act](ref)
+    assert rel_err(base32.float().cpu(), ref) <= TOL[dtype]
+    base16 = None
+    for cfg in (abi.LP_VARIANT_PIPE16_S2A, abi.LP_VARIANT_PIPE16_S2B):
+        eng.set_variant(op, cfg, 3)
+        for rep in range(2):
+            _poison_lds()
+            eng.tensor_view(dst).fill_(float('nan'))
+            _run(eng, B, H, W)
+            out = eng.tensor_view(dst)
+            if base16 is None:
+                base16 = out.clone()
+                assert rel_err(base16.float().cpu(), ref) <= TOL[dtype], (cfg, rel_err(base16.float().cpu(), ref))
+                d = (base16.float() - base32.float()).abs()
+                assert float(d.max()) <= TOL[dtype] * float(ref.abs().max()) and float((d > 0).float().mean()) < 0.25
+            assert torch.equal(out, base16), (cfg, rep, int((out != base16).sum()), int(torch.isnan(out.float()).sum()))
+
+
 RING_CASES = [
     # (cin, cout, h, w, B): ONE K-chunk per tile (every chunk of the stream crosses a tile boundary: the DMA tile iterator and the
     # per-tile halo map advance once per chunk) and at least three tiles per persistent workgroup, ragged maps included

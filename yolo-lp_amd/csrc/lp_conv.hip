@@ -131,18 +131,19 @@ int conv_pick_pitch16(const ConvShape& s, int TH, int TW) {
     return best;
 }
 
-void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW) {
+void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW, int stride) {
     struct Cand { double cost; int th, tw; };
     Cand best[4];
     int n = 0;
     const int ncu = device_cus();
     for (int th = 1; th <= Ho; ++th)
         for (int tw = 1; tw <= Wo; ++tw) {
-            if (th * tw > s.PB || (th + 2) * (tw + 2) > s.HPMAX) continue;
+            const int hh = (th - 1) * stride + 3, hw = (tw - 1) * stride + 3;     // halo of the tile (stride 2: lp_conv3x3_s2p16.inc)
+            if (th * tw > s.PB || hh * hw > s.HPMAX) continue;
             const long tiles = (long)B * ceil_div(Ho, th) * ceil_div(Wo, tw) * nct;
             const int nb = ceil_div(th * tw, 16), per_wave = ceil_div(nb, s.WGP);
             // time ~ (tiles per workgroup) x (K-step length: the busiest wave's blocks + a fixed part) + a little for the halo
-            const double cost = (double)ceil_div((int)tiles, ncu) * (per_wave + 0.75) + 1e-4 * (th + 2) * (tw + 2) + 1e-7 * tiles;
+            const double cost = (double)ceil_div((int)tiles, ncu) * (per_wave + 0.75) + 1e-4 * hh * hw + 1e-7 * tiles;
             int pos = n < 4 ? n : 4;
             for (int k = 0; k < (n < 4 ? n : 4); ++k)
                 if (cost < best[k].cost) { pos = k; break; }
@@ -248,6 +249,8 @@ ConvShape conv_pipe_shape(int pcfg) {
         case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
         case PIPE16_V0: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 512; s.PB = 4 * 7 * 16; return s;
         case PIPE16_V1: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 512; s.PB = 2 * 7 * 16; return s;
+        case PIPE16_S2A: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 1280; s.PB = 4 * 4 * 16; return s;
+        case PIPE16_S2B: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 1280; s.PB = 2 * 7 * 16; return s;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
     s.PB = 32 * s.WP * s.WGP;
@@ -256,6 +259,8 @@ ConvShape conv_pipe_shape(int pcfg) {
 
 bool conv_pipe_fits(int dtype, int pcfg, int cb_pack, int ksize, int stride, int mode, int nct, int nphase, int nchunks) {
     if (pcfg == PIPE_P) return false;     // the planar stem is chosen by the engine (it replaces the input op as well), never as a variant of a layer
+    if (pipe_is_16s2(pcfg))               // the stride-2 kernel: any number of K-chunks (five K-steps per chunk), LDS tables of 512 couts / 64 chunks
+        return dtype != LP_F32 && ksize == 3 && stride == 2 && mode == MODE_ACT && nphase == 1 && cb_pack == 128 && nct * 128 <= 512 && nchunks >= 1 && nchunks <= 64;
     if (pipe_is_16(pcfg) && (nchunks < 4 || nchunks % 4 != 0)) return false;   // K-steps pair the taps over two chunks, the loop body is two pairs
     if (dtype == LP_F32 || pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg)) || ksize != 3 || stride != 1 || mode != MODE_ACT || nphase != 1) return false;
     const ConvShape s = conv_pipe_shape(pcfg);
@@ -326,6 +331,22 @@ int conv_pipe_launch(int dtype, int pcfg, const ConvArgs& a, hipStream_t st) {
         return fail(LP_ERR_UNSUPPORTED, "planar stem: 16-bit frames only");
     }
     const ConvShape s = conv_pipe_shape(pcfg);
+    if (pipe_is_16s2(pcfg)) {             // stride 2: its own geometry (lp_conv3x3_s2p16.inc); the kernel indexes LDS and global memory from these
+        const int hh2 = 2 * a.TH + 1, hw2 = 2 * a.TW + 1, nchunks = a.chunk_begin[a.nsrc];
+        if (a.TH < 1 || a.TW < 1 || a.TH * a.TW > s.PB || a.hpitch != hw2 || hh2 * a.hpitch > s.HPMAX)
+            return fail(LP_ERR_ARG, "conv3x3 s2p16: tile does not fit the kernel configuration");
+        if (a.tiles_x * a.TW < a.Wo || a.tiles_y * a.TH < a.Ho) return fail(LP_ERR_ARG, "conv3x3 s2p16: tiles do not cover the output");
+        if (a.nsrc < 1 || a.nsrc > LP_MAX_SRC || a.nct < 1 || a.nct * s.CB > 512 || nchunks < 1 || nchunks > 64 || a.nphase != 1 || a.out_scale != 1 ||
+            a.H != 2 * a.Ho || a.W != 2 * a.Wo || a.out2)
+            return fail(LP_ERR_ARG, "conv3x3 s2p16: not a 3x3 stride-2 layer this kernel runs");
+        const int stride = a.out_pix_stride > a.res_cs ? a.out_pix_stride : a.res_cs;
+        if (((long long)a.TH * a.Wo + a.TW) * stride + 2048 >= (1ll << 31)) return fail(LP_ERR_ARG, "conv3x3 s2p16: a tile's rows span more than 2^31 elements");
+        switch (dtype) {
+            case LP_F16: return conv_pipe_launch_f16(pcfg, a, device_cus(), st);
+            case LP_BF16: return conv_pipe_launch_bf16(pcfg, a, device_cus(), st);
+        }
+        return fail(LP_ERR_UNSUPPORTED, "conv3x3 s2p16: 16-bit activations only");
+    }
     const int hh = a.TH + 2, hw = a.TW + 2;
     if (pcfg < 0 || (pcfg >= PIPE_COUNT && !pipe_is_16(pcfg))) return fail(LP_ERR_ARG, "conv3x3 pipe: configuration");
     if (pipe_is_16(pcfg) && (a.chunk_begin[a.nsrc] < 4 || a.chunk_begin[a.nsrc] % 4 != 0)) return fail(LP_ERR_ARG, "conv3x3 pipe16: K-chunks not a multiple of four");

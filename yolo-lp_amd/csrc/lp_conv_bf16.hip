@@ -6,6 +6,7 @@
 #include "lp_conv3x3_pipe.inc"
 #include "lp_conv3x3_pipe16.inc"
 #include "lp_conv3x3_pipe16v.inc"
+#include "lp_conv3x3_s2p16.inc"
 #include "lp_stem_planar.inc"
 #include "lp_stem2_fused.inc"
 #include "lp_pw_s2_fused.inc"
@@ -24,6 +25,7 @@ int conv_pipe_launch_bf16(int pcfg, const ConvArgs& a, int ncu, hipStream_t st) 
     if (pcfg == PIPE_FUSED2) return stem2_fused_launch<bf16>(a, ncu, st);
     if (pcfg == PIPE_FUSED_PW) return pw_s2_fused_launch<bf16>(a, ncu, st);
     if (pcfg == PIPE_FUSED_BF) return bifusion_launch_dtype<bf16>(a, ncu, st);
+    if (pipe_is_16s2(pcfg)) return s2p16_launch_dtype<bf16>(pcfg, a, ncu, st);
     if (pipe_is_16v(pcfg)) return pipe16v_launch_dtype<bf16>(pcfg, a, ncu, st);
     if (pipe_is_16(pcfg)) return pipe16_launch_dtype<bf16>(pcfg, a, ncu, st);
     return pcfg == PIPE_P ? stem_planar_launch<bf16>(a, ncu, st) : pipe_launch_dtype<bf16>(pcfg, a, ncu, st);

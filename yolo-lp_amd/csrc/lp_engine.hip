@@ -106,6 +106,7 @@ struct lp_engine {
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
     bool single_lane = true;          // lp_engine_set_single_lane (default): every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
+    bool s2p16 = getenv("LP_NO_S2P16") == nullptr;     // with mfma16: eligible 3x3 STRIDE-2 layers run on conv3x3_s2p16_kernel (op_fam16)
     bool mfma16 = getenv("LP_NO_MFMA16") == nullptr;   // lp_engine_set_mfma16: eligible 3x3 layers run on the 16x16x32 family (op_fam16)
     // Detections-only forward: the box predictors of a level may run for the level's CANDIDATES only (head_box_det_kernel, sparse form) when,
     // in op order, exactly the class predictors of the same level sit between a box op and the box op before it -- then the entries
@@ -735,10 +736,13 @@ static bool det_fits(const lp_engine* e, const Op& op) {
 // layer alone (3x3 stride 1, 16-bit, K-chunks a multiple of four, 128-row weight packing: more than 64 stored output channels).  Inside a family the variants (tile
 // shapes, wave grids) are bit-identical and the autotuner picks by time.
 static bool op_fam16(const lp_engine* e, const Op& op) {
-    if (!e->mfma16 || e->dtype == LP_F32 || op.kind != OP_CONV || op.ksize != 3 || op.stride != 1 || op.mode != MODE_ACT) return false;
+    if (!e->mfma16 || e->dtype == LP_F32 || op.kind != OP_CONV || op.ksize != 3 || op.mode != MODE_ACT) return false;
+    if (op.stride == 2)       // stride 2 (lp_conv3x3_s2p16.inc): 128-row packing, one destination; LP_NO_S2P16=1 keeps these layers on conv_mfma_kernel
+        return e->s2p16 && op.dst2 < 0 && conv_pipe_fits(e->dtype, PIPE16_S2A, conv_shape(e->dtype, op.cfg, 3, 2).CB, 3, 2, op.mode, op.nct, op.nphase, op.nchunks);
+    if (op.stride != 1) return false;
     return conv_pipe_fits(e->dtype, PIPE16_D, conv_shape(e->dtype, op.cfg, 1, 1).CB, 3, 1, op.mode, op.nct, op.nphase, op.nchunks);
 }
-static int fam16_default_pipe(const lp_engine*, const Op&) { return PIPE16_D + 1; }
+static int fam16_default_pipe(const lp_engine*, const Op& op) { return (op.stride == 2 ? PIPE16_S2A : PIPE16_D) + 1; }
 
 // Launch geometry of one conv-type op for the bound shape and the op's current kernel variant.
 static int prepare_op(lp_engine* e, size_t idx) {
@@ -767,7 +771,10 @@ static int prepare_op(lp_engine* e, size_t idx) {
     a.W = s0.w;
     a.Ho = stv == 2 ? s0.h / 2 : s0.h;
     a.Wo = stv == 2 ? s0.w / 2 : s0.w;
-    if (op.pipe && pipe_is_16v(op.pipe - 1)) {
+    if (op.pipe && pipe_is_16s2(op.pipe - 1)) {
+        conv_pick_tile16v(s, a.Ho, a.Wo, e->B, op.nct, op.tile, &a.TH, &a.TW, 2);
+        a.hpitch = 2 * a.TW + 1;  // halo rows stored evens-first, unswizzled, no padding
+    } else if (op.pipe && pipe_is_16v(op.pipe - 1)) {
         conv_pick_tile16v(s, a.Ho, a.Wo, e->B, op.nct, op.tile, &a.TH, &a.TW);
         a.hpitch = a.TW + 2;      // unswizzled rows: conflict-free for the 16x16 operand map at any pitch
     } else {
@@ -1387,7 +1394,7 @@ extern "C" int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, floa
         int pipe_tile = 0;
         if ((!getenv("LP_NO_PIPE") || fam16) && op.kind == OP_CONV) {
             op.cfg = best_cfg; op.nbuf = best_nb; op.stream_wc = 0;
-            for (int pc = fam16 ? PIPE16_D : 0; pc < (fam16 ? PIPE_END : PIPE_COUNT); ++pc) {
+            for (int pc = fam16 ? PIPE16_D : 0; pc < (fam16 ? PIPE_S2_END : PIPE_COUNT); ++pc) {
                 if (fam16 && !pipe_is_16(pc)) continue;
                 if (!conv_pipe_fits(e->dtype, pc, cb, op.ksize, op.stride, op.mode, op.nct, op.nphase, op.nchunks)) continue;
                 int last_th = -1, last_tw = -1;

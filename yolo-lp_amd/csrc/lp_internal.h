@@ -57,8 +57,11 @@ enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIP
                  PIPE16_D = 7, PIPE16_F = 9 /*D / F on v_mfma_f32_16x16x32 (lp_conv3x3_pipe16.inc): another fp32 summation order,
                                                             chosen per layer by rule, never by timing*/,
                  PIPE16_V0 = 10, PIPE16_V1 = 11 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
-                                                  128 x <= 224*/, PIPE_END = 12 };
-inline bool pipe_is_16(int pcfg) { return pcfg == PIPE16_D || pcfg == PIPE16_F || pcfg == PIPE16_V0 || pcfg == PIPE16_V1; }
+                                                  128 x <= 224*/, PIPE_END = 12,
+                 PIPE16_S2A = 16, PIPE16_S2B = 17 /*3x3 STRIDE 2 on v_mfma_f32_16x16x32, two-slot ring, tiles of any number of 16-pixel blocks
+                                                    (lp_conv3x3_s2p16.inc): 128 couts x <= 256 px (2 x 4 waves), 128 x <= 224 (4 x 2 waves)*/, PIPE_S2_END = 18 };
+inline bool pipe_is_16s2(int pcfg) { return pcfg == PIPE16_S2A || pcfg == PIPE16_S2B; }
+inline bool pipe_is_16(int pcfg) { return pcfg == PIPE16_D || pcfg == PIPE16_F || pcfg == PIPE16_V0 || pcfg == PIPE16_V1 || pipe_is_16s2(pcfg); }
 inline bool pipe_is_16v(int pcfg) { return pcfg == PIPE16_V0 || pcfg == PIPE16_V1; }
 
 struct ConvSrc {
@@ -134,7 +137,7 @@ void conv_pick_tile(const ConvShape& s, int ksize, int stride, int Ho, int Wo, i
 int conv_pick_pitch(const ConvShape& s, int dtype, int ksize, int stride, int TH, int TW);
 int conv_pick_pitch16(const ConvShape& s, int TH, int TW);   // the same for conv3x3_pipe16_kernel's operand map
 // Output tile of conv3x3_pipe16v_kernel (any number of 16-pixel blocks): fewest (rounds of the persistent grid) x (blocks per wave)
-void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW);
+void conv_pick_tile16v(const ConvShape& s, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW, int stride = 1);
 int device_cus();
 int conv_launch(int dtype, int cfg, int mode, int ksize, int stride, int nbuf, const ConvArgs& a, hipStream_t st);
 bool stem_planar_tile(int Ho, int Wo, int choice, int* TH, int* TW);   // lp_stem_planar.inc's output tile (choice = k-th best); false: none

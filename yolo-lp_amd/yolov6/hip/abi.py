@@ -14,6 +14,7 @@ LP_VARIANT_STREAM64, LP_VARIANT_STREAM128, LP_VARIANT_ROWS = 16, 17, 18   # lp_e
 LP_VARIANT_PIPE_D, LP_VARIANT_PIPE_B, LP_VARIANT_PIPE_F, LP_VARIANT_PIPE_C = 32, 33, 34, 35        # pipelined 3x3 stride-1 kernel (nbuf 3)
 LP_VARIANT_PIPE16_D, LP_VARIANT_PIPE16_F = 39, 41                              # the same on v_mfma_f32_16x16x32 (another fp32 summation order)
 LP_VARIANT_PIPE16_V0, LP_VARIANT_PIPE16_V1 = 42, 43                           # ... with tiles of any number of 16-pixel blocks
+LP_VARIANT_PIPE16_S2A, LP_VARIANT_PIPE16_S2B = 48, 49                         # 3x3 stride 2 on v_mfma_f32_16x16x32 (two-slot ring, 16-pixel blocks)
 LP_VARIANT_FUSED_BIFUSION = 45                                                                   # BiFusion's transposed conv + cv1 + cv3 as one kernel
 LP_VARIANT_BOX_SPARSE, LP_VARIANT_BOX_DENSE = 46, 47                                                    # head_box in the detections-only forward: candidates only / every anchor
 LP_VARIANT_FUSED_PW_S2 = 38                                                                      # a 1x1 layer + the 3x3 stride-2 layer behind it as one kernel

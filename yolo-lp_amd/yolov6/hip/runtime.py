@@ -619,7 +619,7 @@ class Engine:
             self.lib.lp_engine_op_variant(self.h, i, ctypes.byref(cfg), ctypes.byref(nb))
             ops.append(dict(kind=('input', 'conv', 'deconv', 'pool', 'head_cls', 'head_box', 'stem')[kind.value], ksize=ks.value,
                             cin=cin.value, cout=cout.value, flops=fl.value, bytes=by.value, ms=float(ms[i]),
-                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 45: 'Fb', 39: 'Md', 41: 'Mf', 42: 'V0', 43: 'V1'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
+                            variant='%s%d' % ({16: 'S', 17: 'W', 18: 'R', 32: 'Pd', 33: 'Pb', 34: 'Pf', 35: 'Pc', 36: 'Pp', 37: 'Fz', 38: 'Fp', 45: 'Fb', 39: 'Md', 41: 'Mf', 42: 'V0', 43: 'V1', 48: 'Xa', 49: 'Xb'}.get(cfg.value) or 'ABCDEFGH'[cfg.value], nb.value)))
         # Ops that launch nothing because a fused kernel carries them (the input op and the stem inside stem2_fused_kernel or behind
         # stem_planar_kernel, the 1x1 layer inside pw_s2_fused_kernel) are folded into their carrier's row: their FLOPs and bytes
         # are work of that kernel, and their own row keeps only the note (an empty event pair -- 1.4 us -- is not a 4 000 TFLOP/s launch).
