@@ -207,12 +207,12 @@ enum { LP_VARIANT_FUSED_BIFUSION = 45 };
  * or for every anchor.  The candidate rows lp_nms_candidates reads are the same bits either way; the sparse form needs one execution lane and the
  * op order cls(level), box(level) per level (else the dense form runs whatever is set).  nbuf is ignored. */
 enum { LP_VARIANT_BOX_SPARSE = 46, LP_VARIANT_BOX_DENSE = 47 };
-/* LP_VARIANT_PIPE16_S2A (48) / _S2B (49): the 3x3 STRIDE-2 layers with 128-row weight packing (more than 64 stored output channels, one
+/* LP_VARIANT_PIPE16_S2A (48) / _S2B (49): a 3x3 STRIDE-2 layer with 128-row weight packing (more than 64 stored output channels, one
  * destination, 16-bit) on v_mfma_f32_16x16x32: persistent workgroups, two-slot LDS ring, tiles of any number of 16-pixel blocks (128 couts x
  * <= 256 px as 2 x 4 waves, 128 x <= 224 as 4 x 2), nbuf 3 (lp_conv3x3_s2p16.inc; reference: efficientrep.py:57-117, common.py:258-259).
- * With lp_engine_set_mfma16 enabled (the default) these layers ALWAYS run on this pair -- their fp32 summation order differs from
- * conv_mfma_kernel<KS=3,S=2>'s, so the choice is a function of the layer, never of timing; LP_NO_S2P16=1 in the environment (read when
- * the engine is created) keeps them on conv_mfma_kernel. */
+ * Another fp32 summation order than conv_mfma_kernel<KS=3,S=2>'s (equal to rounding, not bit for bit).  Measured equal to / slower than
+ * that kernel (profiles/r04_s2p16_convbench.txt): NOT a default and never picked by the autotuner -- lp_engine_set_op_variant selects it for
+ * one op; an engine created under LP_S2P16=1 runs every eligible layer on it (by rule, never by timing). */
 enum { LP_VARIANT_PIPE16_S2A = 48, LP_VARIANT_PIPE16_S2B = 49 };
 int lp_engine_op_carrier(const lp_engine* e, int op, int frame_direct);
 int lp_engine_autotune(lp_engine* e, const void* x, int x_dtype, float* pred, void* stream, int reps);

@@ -106,7 +106,7 @@ struct lp_engine {
     hipEvent_t fork_ev = nullptr, join_ev[LP_MAX_LANES] = {};
     bool single_lane = true;          // lp_engine_set_single_lane (default): every op on the caller's stream, in op order
     bool use_graph = false;           // lp_engine_set_graph: replay the captured forward instead of re-issuing ~80 launches
-    bool s2p16 = getenv("LP_NO_S2P16") == nullptr;     // with mfma16: eligible 3x3 STRIDE-2 layers run on conv3x3_s2p16_kernel (op_fam16)
+    bool s2p16 = getenv("LP_S2P16") != nullptr;        // opt-in (measured equal / slower: lp_conv3x3_s2p16.inc): with mfma16, eligible 3x3 STRIDE-2 layers run on conv3x3_s2p16_kernel (op_fam16)
     bool mfma16 = getenv("LP_NO_MFMA16") == nullptr;   // lp_engine_set_mfma16: eligible 3x3 layers run on the 16x16x32 family (op_fam16)
     // Detections-only forward: the box predictors of a level may run for the level's CANDIDATES only (head_box_det_kernel, sparse form) when,
     // in op order, exactly the class predictors of the same level sit between a box op and the box op before it -- then the entries
@@ -737,7 +737,7 @@ static bool det_fits(const lp_engine* e, const Op& op) {
 // shapes, wave grids) are bit-identical and the autotuner picks by time.
 static bool op_fam16(const lp_engine* e, const Op& op) {
     if (!e->mfma16 || e->dtype == LP_F32 || op.kind != OP_CONV || op.ksize != 3 || op.mode != MODE_ACT) return false;
-    if (op.stride == 2)       // stride 2 (lp_conv3x3_s2p16.inc): 128-row packing, one destination; LP_NO_S2P16=1 keeps these layers on conv_mfma_kernel
+    if (op.stride == 2)       // stride 2 (lp_conv3x3_s2p16.inc): 128-row packing, one destination; only in engines created under LP_S2P16=1
         return e->s2p16 && op.dst2 < 0 && conv_pipe_fits(e->dtype, PIPE16_S2A, conv_shape(e->dtype, op.cfg, 3, 2).CB, 3, 2, op.mode, op.nct, op.nphase, op.nchunks);
     if (op.stride != 1) return false;
     return conv_pipe_fits(e->dtype, PIPE16_D, conv_shape(e->dtype, op.cfg, 1, 1).CB, 3, 1, op.mode, op.nct, op.nphase, op.nchunks);
