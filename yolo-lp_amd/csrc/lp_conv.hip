@@ -249,8 +249,8 @@ ConvShape conv_pipe_shape(int pcfg) {
         case PIPE_C: s.CB = 32; s.WGC = 1; s.WGP = 8; s.HPMAX = 736; break;
         case PIPE16_V0: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 512; s.PB = 4 * 7 * 16; return s;
         case PIPE16_V1: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 512; s.PB = 2 * 7 * 16; return s;
-        case PIPE16_S2A: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 1280; s.PB = 4 * 4 * 16; return s;
-        case PIPE16_S2B: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 1280; s.PB = 2 * 7 * 16; return s;
+        case PIPE16_S2A: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 864; s.PB = 4 * 4 * 16; return s;
+        case PIPE16_S2B: s.CB = 128; s.WGC = 4; s.WGP = 2; s.HPMAX = 864; s.PB = 2 * 7 * 16; return s;
         default: s.CB = 128; s.WGC = 2; s.WGP = 4; s.HPMAX = 384; break;
     }
     s.PB = 32 * s.WP * s.WGP;
