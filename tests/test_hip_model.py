@@ -184,6 +184,36 @@ def test_full_model_fp16_vs_oracle_and_determinism():
     assert torch.equal(p3[0], p1[1])
 
 
+def test_full_model_fp16_with_the_stride2_family(monkeypatch):
+    """LP_S2P16=1 (read when an engine is created): every eligible 3x3 stride-2 layer on conv3x3_s2p16_kernel, chosen by
+    rule.  The same bars as the default engine: the fp32 oracle within the fp16 tolerance, bitwise reproducible, image k of a batch =
+    image k alone; and the engine really runs the kernel (variant 48 / 49 on at least three ops of yololps)."""
+    import ctypes
+    from oracle import lp_oracle
+    from yolov6.hip import abi, runtime
+    from yolov6.utils.synth import build_synthetic
+    monkeypatch.setenv('LP_S2P16', '1')
+    m = build_synthetic(CFG('yololps'), sigma=0.25)
+    x = torch.rand(2, 3, 640, 640, generator=torch.Generator().manual_seed(1234))
+    ref, _ = lp_oracle.forward(m.state_dict(), lp_oracle.arch('yololps'), x)
+    mh = m.cuda().half()
+    with torch.no_grad():
+        p1, _ = mh(x.cuda().half())
+        p1 = p1.clone()
+        p2, _ = mh(x.cuda().half())
+        p3, _ = mh(x[1:2].cuda().half())
+    eng = runtime.engine_for(mh)
+    on = 0
+    for i in range(eng.lib.lp_engine_num_ops(eng.h)):
+        cfg, nb = ctypes.c_int(), ctypes.c_int()
+        abi.check(eng.lib.lp_engine_op_variant(eng.h, i, ctypes.byref(cfg), ctypes.byref(nb)), 'lp_engine_op_variant')
+        on += cfg.value in (abi.LP_VARIANT_PIPE16_S2A, abi.LP_VARIANT_PIPE16_S2B)
+    assert on >= 3, on
+    assert torch.equal(p1, p2)
+    assert torch.equal(p3[0], p1[1])
+    _check_pred(p1.cpu(), ref, 640, 2.4e-3, 9e-3, 'fp16 full yololps, stride-2 family')
+
+
 def _prepared(name, dtype, sigma):
     """The reference's inference preparation (inferer.py:25-68): float -> fuse_model -> switch_to_deploy -> half."""
     from yolov6.utils.synth import build_synthetic
