@@ -229,10 +229,10 @@ def test_hand_scheduled_kernels_of_the_product_build_pass_the_asm_audit():
     sys.path.insert(0, os.path.join(REPO, 'tools'))
     import asm_audit
     from yolov6.hip import abi
-    pats = ('conv3x3_pipe', 'stem2_fused_kernel', 'pw_s2_fused_kernel', 'stem_planar_kernel', 'head_det_kernel', 'head_cls_rows_kernel',
+    pats = ('conv3x3_pipe', 'conv3x3_s2p16', 'stem2_fused_kernel', 'pw_s2_fused_kernel', 'stem_planar_kernel', 'head_det_kernel', 'head_cls_rows_kernel',
             'head_box_det_kernel')
     res = asm_audit.audit_file(abi.LIB_PATH, pats)
-    assert sum('conv3x3_pipe' in k for k in res) >= 16 and len(res) >= 50, sorted(res)[:5]
+    assert sum('conv3x3_pipe' in k for k in res) >= 16 and sum('conv3x3_s2p16' in k for k in res) == 4 and len(res) >= 54, sorted(res)[:5]
     bad = {k: v[:3] for k, (n, v) in res.items() if v}
     assert not bad, bad
 
