@@ -208,7 +208,7 @@ enum { LP_VARIANT_FUSED_BIFUSION = 45 };
  * op order cls(level), box(level) per level (else the dense form runs whatever is set).  nbuf is ignored. */
 enum { LP_VARIANT_BOX_SPARSE = 46, LP_VARIANT_BOX_DENSE = 47 };
 /* LP_VARIANT_PIPE16_S2A (48) / _S2B (49): a 3x3 STRIDE-2 layer with 128-row weight packing (more than 64 stored output channels, one
- * destination, 16-bit) on v_mfma_f32_16x16x32: persistent workgroups, two-slot LDS ring, tiles of any number of 16-pixel blocks (128 couts x
+ * destination, 16-bit) on v_mfma_f32_16x16x32: persistent workgroups, three halo + two weight LDS slots (the halo requested two chunks ahead, counted vmcnt), tiles of any number of 16-pixel blocks (128 couts x
  * <= 256 px as 2 x 4 waves, 128 x <= 224 as 4 x 2), nbuf 3 (lp_conv3x3_s2p16.inc; reference: efficientrep.py:57-117, common.py:258-259).
  * Another fp32 summation order than conv_mfma_kernel<KS=3,S=2>'s (equal to rounding, not bit for bit).  Measured equal to / slower than
  * that kernel (profiles/r04_s2p16_convbench.txt): NOT a default and never picked by the autotuner -- lp_engine_set_op_variant selects it for

@@ -629,7 +629,7 @@ S2P16_CASES = [
 def test_conv3x3_s2p16(case, dtype):
     """The 3x3 stride-2 kernel on v_mfma_f32_16x16x32 (LP_VARIANT_PIPE16_S2A / _S2B, lp_conv3x3_s2p16.inc): within the stated
     tolerance of F.conv2d in fp32 and of conv_mfma_kernel<KS=3,S=2> (another fp32 summation order, so not bit for bit), its two wave
-    grids bit-identical to each other, every launch reproducible with a poisoned LDS in front of it (two-slot ring, tiles with one,
+    grids bit-identical to each other, every launch reproducible with a poisoned LDS in front of it (three halo + two weight slots, counted vmcnt; tiles with one,
     three and sixteen chunks)."""
     from yolov6.hip import abi
     cins, cout, act, h, w, B = case
