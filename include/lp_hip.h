@@ -210,8 +210,8 @@ enum { LP_VARIANT_BOX_SPARSE = 46, LP_VARIANT_BOX_DENSE = 47 };
 /* LP_VARIANT_PIPE16_S2A (48) / _S2B (49): a 3x3 STRIDE-2 layer with 128-row weight packing (more than 64 stored output channels, one
  * destination, 16-bit) on v_mfma_f32_16x16x32: persistent workgroups, three halo + two weight LDS slots (the halo requested two chunks ahead, counted vmcnt), tiles of any number of 16-pixel blocks (128 couts x
  * <= 256 px as 2 x 4 waves, 128 x <= 224 as 4 x 2), nbuf 3 (lp_conv3x3_s2p16.inc; reference: efficientrep.py:57-117, common.py:258-259).
- * Another fp32 summation order than conv_mfma_kernel<KS=3,S=2>'s (equal to rounding, not bit for bit).  Measured equal to / slower than
- * that kernel (profiles/r04_s2p16_convbench.txt): NOT a default and never picked by the autotuner -- lp_engine_set_op_variant selects it for
+ * Another fp32 summation order than conv_mfma_kernel<KS=3,S=2>'s (equal to rounding, not bit for bit).  Measured 0-9 % faster than that
+ * kernel per layer and equal over the whole step (profiles/r04_s2p16_convbench.txt, r04_experiments.txt 15): NOT a default and never picked by the autotuner -- lp_engine_set_op_variant selects it for
  * one op; an engine created under LP_S2P16=1 runs every eligible layer on it (by rule, never by timing). */
 enum { LP_VARIANT_PIPE16_S2A = 48, LP_VARIANT_PIPE16_S2B = 49 };
 int lp_engine_op_carrier(const lp_engine* e, int op, int frame_direct);
