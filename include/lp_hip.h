@@ -298,6 +298,11 @@ int lp_debug_poison_lds(void* stream);
  * slot) or of stem2_fused_kernel (fused != 0: TW even, TH * TW <= 128, frame window <= 21 KiB, stem tile pitch *hpitch >= 2 TW + 1 with
  * (2 TH + 1) * pitch <= 640 positions).  LP_ERR_UNSUPPORTED: no such tile. */
 int lp_plan_stem_tile(int fused, int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch);
+/* The same for the block-tiled 3x3 kernels: the `choice`-th best output tile of LP_VARIANT_PIPE16_V0 / _V1 (stride 1) or LP_VARIANT_PIPE16_S2A / _S2B
+ * (stride 2) for B images of an Ho x Wo OUTPUT map and nct cout tiles -- TH * TW pixels within the variant's pixel blocks, the halo
+ * ((TH - 1) s + 3) x ((TW - 1) s + 3) within its LDS slot, fewest rounds of the persistent grid first; *hpitch = the halo row pitch.
+ * LP_ERR_UNSUPPORTED: another variant. */
+int lp_plan_block_tile(int variant, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW, int* hpitch);
 
 #ifdef __cplusplus
 }

@@ -237,6 +237,35 @@ def test_hand_scheduled_kernels_of_the_product_build_pass_the_asm_audit():
     assert not bad, bad
 
 
+def test_block_tile_planning_respects_the_kernels_limits():
+    """lp_plan_block_tile: the tiles the engine hands to conv3x3_pipe16v_kernel (stride 1) and conv3x3_s2p16_kernel (stride 2) stay inside
+    the variant's pixel blocks and halo slot, and for the layers of the 640x640 network (32 images) they fill the 256 workgroups in whole
+    rounds -- the reason these kernels exist."""
+    from yolov6.hip import abi
+    lib = abi.load()
+    th, tw, hp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    limits = {abi.LP_VARIANT_PIPE16_V0: (448, 512, 1), abi.LP_VARIANT_PIPE16_V1: (224, 512, 1),
+              abi.LP_VARIANT_PIPE16_S2A: (256, 864, 2), abi.LP_VARIANT_PIPE16_S2B: (224, 864, 2)}
+    for variant, (pb, hpmax, s) in limits.items():
+        for ho, wo, B, nct in [(40, 40, 32, 2), (80, 80, 32, 1), (20, 20, 32, 4), (160, 160, 32, 1), (17, 11, 3, 2), (1, 1, 1, 1), (5, 252, 7, 1), (160, 160, 8, 3)]:
+            seen = set()
+            for choice in range(3):
+                assert lib.lp_plan_block_tile(variant, ho, wo, B, nct, choice, ctypes.byref(th), ctypes.byref(tw), ctypes.byref(hp)) == 0
+                t = (th.value, tw.value)
+                assert 1 <= t[0] <= ho and 1 <= t[1] <= wo and t[0] * t[1] <= pb, (variant, ho, wo, t)
+                assert hp.value == (t[1] - 1) * s + 3 and ((t[0] - 1) * s + 3) * hp.value <= hpmax, (variant, ho, wo, t)
+                seen.add(t)
+            assert len(seen) >= 1
+    # whole rounds of 256 workgroups on the layers these variants were built for (first choice)
+    for variant, ho, wo, nct, rounds in [(abi.LP_VARIANT_PIPE16_V0, 40, 40, 2, 1), (abi.LP_VARIANT_PIPE16_V0, 80, 80, 1, 2), (abi.LP_VARIANT_PIPE16_V1, 20, 20, 4, 1),
+                                         (abi.LP_VARIANT_PIPE16_S2A, 40, 40, 2, 2), (abi.LP_VARIANT_PIPE16_S2A, 20, 20, 4, 1), (abi.LP_VARIANT_PIPE16_S2A, 80, 80, 1, 5)]:
+        assert lib.lp_plan_block_tile(variant, ho, wo, 32, nct, 0, ctypes.byref(th), ctypes.byref(tw), None) == 0
+        tiles = 32 * -(-ho // th.value) * -(-wo // tw.value) * nct
+        assert tiles == rounds * 256, (variant, ho, wo, th.value, tw.value, tiles)
+    assert lib.lp_plan_block_tile(abi.LP_VARIANT_PIPE_D, 40, 40, 32, 2, 0, ctypes.byref(th), ctypes.byref(tw), None) < 0
+    assert lib.lp_plan_block_tile(abi.LP_VARIANT_PIPE16_V0, 0, 40, 32, 2, 0, ctypes.byref(th), ctypes.byref(tw), None) < 0
+
+
 def test_engine_cache_stays_out_of_the_module_state():
     """the cached engine must not ride along in ``Model.__dict__`` -- the reference's checkpoint format pickles
     whole modules and EMA / get_model_info deep-copy them (checkpoint.py:22-32)."""

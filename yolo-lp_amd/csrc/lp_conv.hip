@@ -416,6 +416,19 @@ int head_rows_launch(int dtype, const ConvArgs& a, int cb_pack, hipStream_t st) 
 
 }  // namespace lp
 
+// Host-side planning of the block-tiled 3x3 kernels (conv3x3_pipe16v_kernel, conv3x3_s2p16_kernel), exported for the CPU tests of the host logic
+// (no device needed: without one the grid is taken as 256 workgroups).
+extern "C" int lp_plan_block_tile(int variant, int Ho, int Wo, int B, int nct, int choice, int* TH, int* TW, int* hpitch) {
+    const int pcfg = variant - LP_VARIANT_PIPE_D;
+    if (!TH || !TW || Ho < 1 || Wo < 1 || B < 1 || nct < 1) return lp::fail(LP_ERR_ARG, "lp_plan_block_tile: bad arguments");
+    if (!lp::pipe_is_16v(pcfg) && !lp::pipe_is_16s2(pcfg)) return lp::fail(LP_ERR_UNSUPPORTED, "lp_plan_block_tile: not a block-tiled variant");
+    const lp::ConvShape s = lp::conv_pipe_shape(pcfg);
+    const int stride = lp::pipe_is_16s2(pcfg) ? 2 : 1;
+    lp::conv_pick_tile16v(s, Ho, Wo, B, nct, choice, TH, TW, stride);
+    if (hpitch) *hpitch = (*TW - 1) * stride + 3;
+    return LP_OK;
+}
+
 // Host-side planning of the two frame-reading stem kernels, exported for the CPU tests of the host logic (no device needed).
 extern "C" int lp_plan_stem_tile(int fused, int Ho, int Wo, int choice, int* TH, int* TW, int* hpitch) {
     if (!TH || !TW || Ho < 1 || Wo < 1) return lp::fail(LP_ERR_ARG, "lp_plan_stem_tile: bad arguments");

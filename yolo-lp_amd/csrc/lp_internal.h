@@ -58,7 +58,7 @@ enum PipeCfgId { PIPE_D = 0 /*128 couts x 256 px*/, PIPE_B = 1 /*64 x 512*/, PIP
                                                             chosen per layer by rule, never by timing*/,
                  PIPE16_V0 = 10, PIPE16_V1 = 11 /*the same sums with tiles of any number of 16-pixel blocks (lp_conv3x3_pipe16v.inc): 128 couts x <= 448 px,
                                                   128 x <= 224*/, PIPE_END = 12,
-                 PIPE16_S2A = 16, PIPE16_S2B = 17 /*3x3 STRIDE 2 on v_mfma_f32_16x16x32, two-slot ring, tiles of any number of 16-pixel blocks
+                 PIPE16_S2A = 16, PIPE16_S2B = 17 /*3x3 STRIDE 2 on v_mfma_f32_16x16x32, three halo + two weight slots, tiles of any number of 16-pixel blocks
                                                     (lp_conv3x3_s2p16.inc): 128 couts x <= 256 px (2 x 4 waves), 128 x <= 224 (4 x 2 waves)*/, PIPE_S2_END = 18 };
 inline bool pipe_is_16s2(int pcfg) { return pcfg == PIPE16_S2A || pcfg == PIPE16_S2B; }
 inline bool pipe_is_16(int pcfg) { return pcfg == PIPE16_D || pcfg == PIPE16_F || pcfg == PIPE16_V0 || pcfg == PIPE16_V1 || pipe_is_16s2(pcfg); }

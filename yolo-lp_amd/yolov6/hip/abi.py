@@ -81,6 +81,7 @@ SYMBOLS = {
     'lp_debug_poison_lds': (c_int, [c_void_p]),
     'lp_check_iou_predicate': (c_int, [c_void_p, ctypes.c_longlong, c_double, c_void_p, c_void_p]),
     'lp_plan_stem_tile': (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'lp_plan_block_tile': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'lp_nms': (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_size_t, c_void_p]),
 }
